@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: equality scan of a 1e9-value 9-bit packed column per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (one scan_eq launch: bitmap + hit count) over the rank's
+row-range shard, the column already resident in HBM.  Weak scaling: every rank owns --rows rows
+(default 1e9; rank r holds global rows [r*rows, (r+1)*rows)); no data-path collective inside the timed
+region.  The RCCL bitmap gather is timed separately after it and reported as `gather_ms`.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 is what a copy achieves
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="values per GPU")
+    ap.add_argument("--bits", type=int, default=9)
+    ap.add_argument("--column", choices=["mod5", "random"], default="mod5",
+                    help="mod5: v=i%%5, key 3 (src/benchmark.cpp:173,:150); random: splitmix64(42,i)&mask, key v[12345]")
+    ap.add_argument("--workload", choices=["scan_eq", "scan_range", "shared_scan", "decompress"], default="scan_eq")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=5)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, col, gpu_bitmap, key):
+    """Reference CPU path on this host's cores, on the SAME column (downloaded from HBM).
+    kind 'reference': oracle/_ref (the reference's scan_256_unrolled, its fastest single-thread variant,
+    src/simd_scan.cpp:273) when the prebuilt .so travelled here; else kind 'port': oracle.c with OpenMP."""
+    import numpy as np
+
+    from oracle import RefLib, oracle, ref_available
+
+    n, c = col.n, col.c
+    packed = col.data.cpu().numpy()
+    nb = (n + 7) // 8
+    gpu_host = gpu_bitmap[:nb].cpu().numpy()
+    if c == 9 and ref_available(9):
+        R = RefLib(9)
+        secs, out, hits = R.scan_timed("scan_256_unrolled", key, packed, n, args.cpu_reps)
+        t = float(np.median(secs))
+        same = bool(np.array_equal(out[:nb], gpu_host))
+        return {"value": n / t, "unit": "values/s", "cores": 1, "kind": "reference",
+                "sample": f"full column ({n} values), scan_256_unrolled, median of {args.cpu_reps} reps, 1 thread",
+                "ms": t * 1e3, "gb_per_s": n * c / 8 / t / 1e9, "bitmap_equals_gpu": same,
+                "host_cpu": _cpu_model(), "host_cores": os.cpu_count()}
+    O = oracle()
+    ts = []
+    for _ in range(max(1, min(args.cpu_reps, 3))):
+        t0 = time.perf_counter()
+        out, hits = O.scan_eq(packed, n, c, key)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    return {"value": n / t, "unit": "values/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"full column ({n} values), oracle.c scalar restatement, OpenMP row-range", "ms": t * 1e3,
+            "bitmap_equals_gpu": bool(np.array_equal(out, gpu_host)), "host_cpu": _cpu_model(),
+            "host_cores": os.cpu_count()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from shared_simd_scan_amd import ScanEngine, kernel_name
+
+    eng = ScanEngine(local_rank)
+    n, c = args.rows, args.bits
+    first = rank * n
+    mask = (1 << c) - 1
+    if args.column == "mod5":
+        col = eng.generate("mod", n, c, 5, first_row=first)
+        key = 3
+    else:
+        col = eng.generate("splitmix", n, c, 42, first_row=first)
+        import numpy as np
+
+        from oracle import oracle  # key = v[12345] of the global column
+        key = int(oracle().gen_values("splitmix", 1, c, 42, first=12345)[0])
+    nb = (n + 7) // 8
+    keys8 = list(range(8))
+
+    if args.workload == "scan_eq":
+        bitmap, hits = eng.alloc_bitmap(n), torch.zeros(1, dtype=torch.int64, device="cuda")
+        step = lambda: eng.scan(key, col, bitmap=bitmap, hits=hits)  # noqa: E731
+        algo_bytes = n * c / 8 + n / 8
+        kname = kernel_name("scan_eq", c)
+    elif args.workload == "scan_range":
+        bitmap, hits = eng.alloc_bitmap(n), torch.zeros(1, dtype=torch.int64, device="cuda")
+        lo, hi = (1 << c) // 4, (1 << c) // 2
+        step = lambda: eng.scan_range(lo, hi, col, bitmap=bitmap, hits=hits)  # noqa: E731
+        algo_bytes = n * c / 8 + n / 8
+        kname = kernel_name("scan_range", c)
+    elif args.workload == "shared_scan":
+        stride = (nb + 15) // 16 * 16
+        bitmap = torch.empty((8, stride), dtype=torch.uint8, device="cuda")
+        hits = torch.zeros(8, dtype=torch.int64, device="cuda")
+        step = lambda: eng.shared_scan(keys8, col, out=bitmap, hits=hits)  # noqa: E731
+        algo_bytes = n * c / 8 + 8 * n / 8
+        kname = kernel_name("shared_scan", c)
+    else:
+        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        bitmap, hits = out, None
+        step = lambda: eng.decompress(col, out=out)  # noqa: E731
+        algo_bytes = n * c / 8 + 4 * n
+        kname = kernel_name("decompress", c)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the stream the kernels ran on
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        d = torch.tensor([dev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(d, op=dist.ReduceOp.MAX)
+        dev_ms = float(d.item())
+
+    # correctness of what was timed
+    expect_hits = None
+    if args.workload == "scan_eq" and args.column == "mod5":
+        lo_r, hi_r = first, first + n
+        expect_hits = (hi_r - 3 + 4) // 5 - (lo_r - 3 + 4) // 5  # rows i in [lo,hi) with i%5==3
+        got = int(hits.item())
+        assert got == expect_hits, f"hits {got} != {expect_hits}"
+
+    gather_ms = None
+    if world > 1 and not args.no_gather and args.workload in ("scan_eq", "scan_range"):
+        # final exchange step of the north star: per-shard bitmaps -> rank 0 (RCCL over xGMI)
+        from shared_simd_scan_amd.sharded import gather_bitmaps
+
+        full = gather_bitmaps(bitmap[:nb], dst=0)  # warm
+        sync_all()
+        g0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            full = gather_bitmaps(bitmap[:nb], dst=0, out=full)
+        sync_all()
+        gather_ms = (time.perf_counter() - g0) / reps * 1e3
+        g = torch.tensor([gather_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(g, op=dist.ReduceOp.MAX)
+        gather_ms = float(g.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * n / (elapsed / args.steps)
+        achieved = algo_bytes / (dev_ms * 1e-3) / 1e9
+        line = {
+            "metric": "scanned values/sec (equality scan, 9-bit packed column, bitmap + hit count out)"
+            if args.workload == "scan_eq" else f"{args.workload} values/sec",
+            "value": value, "unit": "values/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32" if args.workload != "decompress" else "i32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} {n:.0e}x{c}bit per GPU, column={args.column}, key={key}",
+                       "rows_per_gpu": n, "bits": c, "parallelism": f"row-range shards x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(args, kname),
+                         "kernel": kname, "kernel_ms": dev_ms, "algorithmic_bytes": algo_bytes,
+                         "read_gb_per_s": n * c / 8 / (dev_ms * 1e-3) / 1e9},
+            "hits": int(hits.sum().item()) if hits is not None else None,
+        }
+        if gather_ms is not None:
+            line["gather_ms"] = gather_ms
+            line["gather_gb_per_s"] = (world - 1) * nb / (gather_ms * 1e-3) / 1e9
+            line["end_to_end_values_per_s"] = world * n / ((ms_per_step + gather_ms) * 1e-3)
+        if world == 1 and not args.no_cpu_baseline and args.workload == "scan_eq":
+            line["cpu_baseline"] = cpu_baseline(args, col, bitmap, key)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(args, kname):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc.json), collected and
+    corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950, separate passes).  null when no
+    matching profile is committed for this workload/size."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    key = f"{args.workload}:{args.rows}:{args.bits}"
+    ent = table.get(key)
+    return ent.get("hbm_bytes_per_launch") if ent else None
+
+
+if __name__ == "__main__":
+    main()

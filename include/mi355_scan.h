@@ -1,0 +1,149 @@
+/*
+ * mi355_scan.h -- C ABI of libmi355scan.so: MI355X (gfx950) engine for bit-packed column
+ * decompress / predicate scan / shared multi-predicate scan.
+ *
+ * This is the drop-in boundary for the hot path of RRr89/Shared_SIMD_Scan.  The reference has no
+ * FFI layer: its boundary is the set of C++ free functions declared in src/simd_scan.hpp:20-123.
+ * Each entry point below names the reference interface it replaces ("replaces:" lines, paths
+ * relative to the reference repository).  include/simd_scan.hpp maps the reference's C++ names
+ * onto this ABI; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns an int status (MI355_OK == 0);
+ *     mi355_last_error() gives the message of the calling thread's last failure.
+ *   - `c` is the bit width (the reference's compile-time BITS_NEEDED, src/simd_scan.hpp:12),
+ *     1..32, passed at run time.  `n` is always a number of VALUES, never bytes (as in the
+ *     reference).  Counts are 64-bit (the reference returns `int hits`, src/simd_scan.hpp:89).
+ *   - packed format: value i occupies bits [c*i, c*i+c) of a little-endian byte stream, LSB
+ *     first (src/simd_scan_compression.cpp:53-104).  A packed buffer must be at least
+ *     mi355_compressed_buffer_size(c, n) bytes (payload + 256 B pad, src/simd_scan.hpp:20-26);
+ *     device packed buffers must be 16-byte aligned.
+ *   - bitmap format: bit i = byte i/8, bit i%8 (src/util.cpp:51-58).  The engine writes exactly
+ *     ceil(n/8) bytes; bits >= n of the last byte are 0; hits = popcount over [0, n).  (The
+ *     reference's variants disagree with each other past n; see DESIGN.md "tail rule".)
+ *   - keys are signed 32-bit and compared unmasked: a key outside [0, 2^c) matches nothing
+ *     (reference behaviour, SURVEY 8c hazard 5).
+ *   - *_dev functions take DEVICE pointers, enqueue on the context's stream and return without
+ *     synchronising; the others take HOST pointers, copy in/out and return when done.
+ *   - there is no CPU fallback: without a usable gfx950 device every compute entry point fails
+ *     with MI355_E_NODEVICE / MI355_E_HIP.
+ */
+#ifndef MI355_SCAN_H
+#define MI355_SCAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define MI355_API __attribute__((visibility("default")))
+#else
+#define MI355_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK 0
+#define MI355_E_INVALID (-1)  /* bad argument (width, null pointer, alignment, P) */
+#define MI355_E_HIP (-2)      /* a HIP runtime call failed */
+#define MI355_E_NODEVICE (-3) /* no gfx950 device visible */
+
+#define MI355_LAYOUT_PER_PREDICATE 0 /* src/simd_scan_shared.cpp:82  outputs[key][group]      */
+#define MI355_LAYOUT_LINEAR 1        /* src/simd_scan_shared_linear.cpp:57  outputs[group*P+key] */
+
+/* synthetic column kinds for mi355_generate_dev */
+#define MI355_GEN_MOD 0      /* v = (first_row + i) % param           (src/benchmark.cpp:173, :277) */
+#define MI355_GEN_SPLITMIX 1 /* v = splitmix64(seed=param, first_row + i) & (2^c - 1)             */
+#define MI355_GEN_INDEX 2    /* v = (first_row + i) & (2^c - 1)       (src/benchmark.cpp:81)       */
+
+typedef struct mi355_ctx mi355_ctx;
+
+MI355_API const char *mi355_last_error(void);
+MI355_API const char *mi355_version(void);
+
+/* ---- context: device + stream.  ctx == NULL in any call below means the process-wide default
+ * context (device 0, its null stream), created on first use. -------------------------------- */
+MI355_API int mi355_ctx_create(int device, void *hip_stream /* hipStream_t or NULL */, mi355_ctx **out);
+MI355_API int mi355_ctx_destroy(mi355_ctx *ctx);
+MI355_API int mi355_ctx_synchronize(mi355_ctx *ctx);
+MI355_API int mi355_device_count(int *count);
+/* tuning knobs: "max_blocks_per_cu" (0 = occupancy limit), "dma_aux" (cache policy of the HBM->LDS
+ * loads of the equality scan: 0 default, 2 non-temporal) */
+MI355_API int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value);
+
+/* ---- buffer sizing, in bytes.  replaces: compressed_buffer_size / decompression_output_buffer_size
+ * / scan_output_buffer_size (src/simd_scan.hpp:20-40), same formulas. -------------------------- */
+MI355_API size_t mi355_compressed_buffer_size(unsigned c, size_t n);
+MI355_API size_t mi355_decompression_output_buffer_size(size_t n);
+MI355_API size_t mi355_scan_output_buffer_size(size_t n);
+
+/* ---- device memory helpers (hipMalloc / hipMemcpy / hipMemset on the context's device) ------- */
+MI355_API int mi355_dev_alloc(mi355_ctx *ctx, size_t bytes, void **dptr);
+MI355_API int mi355_dev_free(mi355_ctx *ctx, void *dptr);
+MI355_API int mi355_dev_upload(mi355_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+MI355_API int mi355_dev_download(mi355_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+MI355_API int mi355_dev_memset(mi355_ctx *ctx, void *dst_dev, int value, size_t bytes);
+
+/* ---- compression.  replaces: compress_9bit_input (src/simd_scan_compression.cpp:53-104) at any
+ * width.  Values must be < 2^c (the reference does not mask either; the engine masks to c bits
+ * instead of corrupting neighbours).  Writes mi355_compressed_buffer_size(c,n) bytes (pad zeroed). */
+MI355_API int mi355_pack_u16(mi355_ctx *ctx, const uint16_t *values, uint64_t n, unsigned c, void *packed_host);
+MI355_API int mi355_pack_u32(mi355_ctx *ctx, const uint32_t *values, uint64_t n, unsigned c, void *packed_host);
+MI355_API int mi355_pack_u16_dev(mi355_ctx *ctx, const uint16_t *values_dev, uint64_t n, unsigned c, void *packed_dev);
+MI355_API int mi355_pack_u32_dev(mi355_ctx *ctx, const uint32_t *values_dev, uint64_t n, unsigned c, void *packed_dev);
+/* synthesise a packed column on the device from the global row index (no upload): the shapes of
+ * bench_scan / bench_shared_scan / bench_decompression (src/benchmark.cpp:81,:173,:277) */
+MI355_API int mi355_generate_dev(mi355_ctx *ctx, int kind, uint64_t first_row, uint64_t n, unsigned c, uint64_t param,
+                       void *packed_dev);
+
+/* ---- decompression to int32.  replaces: decompress_unvectorized / decompress_128* / decompress_256
+ * / decompress_256_avx2 (src/simd_scan_decompression.cpp, src/simd_scan.hpp:51-73): one kernel, same
+ * result on [0,n).  Writes exactly n ints. ----------------------------------------------------- */
+MI355_API int mi355_decompress(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, int32_t *out_host);
+MI355_API int mi355_decompress_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int32_t *out_dev);
+
+/* ---- equality scan.  replaces: scan_unvectorized / scan_128 / scan_128_unrolled / scan_256 /
+ * scan_256_unrolled (src/simd_scan.cpp, src/simd_scan.hpp:89-96).  hits may be NULL.
+ * _dev: bitmap_dev 16-byte aligned, >= ceil(n/8) bytes; hits_dev is a device uint64, overwritten. */
+MI355_API int mi355_scan_eq(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, int32_t key, uint8_t *bitmap_host,
+                  uint64_t *hits);
+MI355_API int mi355_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int32_t key, void *bitmap_dev,
+                      uint64_t *hits_dev);
+
+/* ---- inclusive range scan lo <= v <= hi.  replaces: the declared-but-unimplemented
+ * `int scan(int predicate_low, int predicate_high, __m128i*, int)` (src/simd_scan.hpp:76-84). */
+MI355_API int mi355_scan_range(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, uint32_t lo, uint32_t hi,
+                     uint8_t *bitmap_host, uint64_t *hits);
+MI355_API int mi355_scan_range_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, uint32_t lo, uint32_t hi,
+                         void *bitmap_dev, uint64_t *hits_dev);
+
+/* ---- shared (multi-predicate) equality scan: P keys, one pass over the column.
+ * replaces (per-predicate outputs): shared_scan_128_{sequential,sequential_unrolled,threaded,standard,
+ *   standard_unrolled,parallel}, shared_scan_256_{sequential,standard,parallel}
+ *   (src/simd_scan_shared.cpp, src/simd_scan.hpp:102-113);
+ * replaces (linear output): shared_scan_128_linear_{standard,simple} and
+ *   shared_scan_128_linear_static<NUM> (src/simd_scan_shared_linear.cpp, src/simd_scan.hpp:119-236).
+ * 1 <= P <= 1024.  hits (P entries) may be NULL.
+ *   host, per-predicate: outputs[k] points at >= ceil(n/8) bytes for key k;
+ *   host, linear:        output holds ceil(n/8)*P bytes, byte of 8-value group g and key k at g*P+k;
+ *   _dev: out_dev is one device buffer; per-predicate bitmaps start at out_dev + k*stride_bytes
+ *         (stride_bytes a multiple of 16, >= ceil(n/8)); linear ignores stride_bytes. */
+MI355_API int mi355_shared_scan_eq(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, const int32_t *keys,
+                         unsigned P, uint8_t *const *outputs, uint64_t *hits);
+MI355_API int mi355_shared_scan_eq_linear(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, const int32_t *keys,
+                                unsigned P, uint8_t *output, uint64_t *hits);
+MI355_API int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const int32_t *keys_host,
+                             unsigned P, int layout, void *out_dev, uint64_t stride_bytes, uint64_t *hits_dev);
+
+/* ---- introspection used by bench.py / tests --------------------------------------------------- */
+/* name of the HIP kernel a given op dispatches to at width c ("scan_eq", "scan_range", "shared_scan",
+ * "decompress", "pack"); returns NULL for unknown ops */
+MI355_API const char *mi355_kernel_name(const char *op, unsigned c);
+/* rows per wave tile of the scan kernels at width c (shard boundaries should be multiples of it) */
+MI355_API uint64_t mi355_tile_values(unsigned c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_SCAN_H */

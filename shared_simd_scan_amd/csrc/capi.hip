@@ -1,0 +1,565 @@
+// capi.hip -- implementation of include/mi355_scan.h (the C ABI of libmi355scan.so).
+//
+// Host-side plumbing only: argument checks, device buffers, stream ordering, kernel dispatch by
+// width.  All arithmetic of the path happens in the HIP kernels of kernels.hpp; there is no CPU
+// implementation of any operation in this library.
+#include "../../include/mi355_scan.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "dispatch.hpp"
+#include "kernels.hpp"
+
+using namespace mi355;
+
+struct mi355_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    int max_blocks_per_cu = 0;
+    int dma_aux = 0;
+    unsigned long long *hits_scratch = nullptr; // 1024 counters
+    int32_t *keys_scratch = nullptr;            // 1024 + 8 keys
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(MI355_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));        \
+    } while (0)
+
+constexpr unsigned kMaxKeys = 1024; // what the reference's linear_simple tops out at (src/simd_scan_shared_linear.cpp:78)
+
+std::mutex g_default_mu;
+mi355_ctx *g_default = nullptr;
+
+int resolve(mi355_ctx *&ctx)
+{
+    if (ctx) return MI355_OK;
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default) {
+        int rc = mi355_ctx_create(0, nullptr, &g_default);
+        if (rc != MI355_OK) return rc;
+    }
+    ctx = g_default;
+    return MI355_OK;
+}
+
+int check_width(unsigned c)
+{
+    if (c < 1 || c > 32) return fail(MI355_E_INVALID, "bit width c=%u outside 1..32", c);
+    return MI355_OK;
+}
+
+typedef hipError_t (*group_fn)(const LaunchReq &);
+const group_fn kGroups[kNumGroups] = {launch_group_0, launch_group_1, launch_group_2, launch_group_3,
+                                      launch_group_4, launch_group_5, launch_group_6, launch_group_7};
+
+int launch(mi355_ctx *ctx, LaunchReq &r)
+{
+    r.stream = ctx->stream;
+    r.num_cus = ctx->num_cus;
+    r.max_blocks_per_cu = ctx->max_blocks_per_cu;
+    r.dma_aux = ctx->dma_aux;
+    hipError_t e = kGroups[(r.c - 1) / 4](r);
+    if (e != hipSuccess) return fail(MI355_E_HIP, "kernel launch (op %d, c=%u): %s", r.op, r.c, hipGetErrorString(e));
+    return MI355_OK;
+}
+
+struct DevBuf { // RAII for the host-pointer (copying) entry points
+    void *p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+};
+
+size_t bitmap_bytes(uint64_t n) { return (size_t)((n + 7) / 8); }
+
+} // namespace
+
+extern "C" {
+
+const char *mi355_last_error(void) { return g_err.c_str(); }
+const char *mi355_version(void) { return "mi355scan 0.1 (gfx950)"; }
+
+int mi355_device_count(int *count)
+{
+    if (!count) return fail(MI355_E_INVALID, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(MI355_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return MI355_OK;
+}
+
+int mi355_ctx_create(int device, void *hip_stream, mi355_ctx **out)
+{
+    if (!out) return fail(MI355_E_INVALID, "out is null");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(MI355_E_NODEVICE, "no HIP device visible: this engine has no CPU fallback");
+    if (device < 0 || device >= n) return fail(MI355_E_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MI355_E_NODEVICE, "device %d is %s; libmi355scan is built for gfx950 (MI355X) only", device,
+                    prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    mi355_ctx *c = new mi355_ctx;
+    c->device = device;
+    c->stream = (hipStream_t)hip_stream;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *s = getenv("MI355_MAX_BLOCKS_PER_CU")) c->max_blocks_per_cu = atoi(s);
+    if (const char *s = getenv("MI355_DMA_AUX")) c->dma_aux = atoi(s);
+    hipError_t e = hipMalloc((void **)&c->hits_scratch, kMaxKeys * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->keys_scratch, (kMaxKeys + 8) * sizeof(int32_t));
+    if (e != hipSuccess) {
+        delete c;
+        return fail(MI355_E_HIP, "hipMalloc(scratch): %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return MI355_OK;
+}
+
+int mi355_ctx_destroy(mi355_ctx *ctx)
+{
+    if (!ctx) return MI355_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->hits_scratch);
+    (void)hipFree(ctx->keys_scratch);
+    {
+        std::lock_guard<std::mutex> lk(g_default_mu);
+        if (g_default == ctx) g_default = nullptr;
+    }
+    delete ctx;
+    return MI355_OK;
+}
+
+int mi355_ctx_synchronize(mi355_ctx *ctx)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+
+int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if (!name) return fail(MI355_E_INVALID, "name is null");
+    if (!strcmp(name, "max_blocks_per_cu"))
+        ctx->max_blocks_per_cu = value;
+    else if (!strcmp(name, "dma_aux"))
+        ctx->dma_aux = value;
+    else
+        return fail(MI355_E_INVALID, "unknown option %s", name);
+    return MI355_OK;
+}
+
+/* ---- sizing: src/simd_scan.hpp:20-40 ---- */
+size_t mi355_compressed_buffer_size(unsigned c, size_t n)
+{
+    size_t bits = (size_t)c * n;
+    return bits / 8 + (bits % 8 != 0) + 256;
+}
+size_t mi355_decompression_output_buffer_size(size_t n) { return n * 4 + 32; }
+size_t mi355_scan_output_buffer_size(size_t n) { return n / 8 + (n % 8 != 0) + 32; }
+
+/* ---- device memory ---- */
+int mi355_dev_alloc(mi355_ctx *ctx, size_t bytes, void **dptr)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if (!dptr) return fail(MI355_E_INVALID, "dptr is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
+    return MI355_OK;
+}
+int mi355_dev_free(mi355_ctx *ctx, void *dptr)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipFree(dptr));
+    return MI355_OK;
+}
+int mi355_dev_upload(mi355_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+int mi355_dev_download(mi355_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+int mi355_dev_memset(mi355_ctx *ctx, void *dst_dev, int value, size_t bytes)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+    return MI355_OK;
+}
+
+/* ---- pack / generate ---- */
+static int pack_launch(mi355_ctx *ctx, int src, const void *values_dev, uint64_t n, uint64_t first_row, uint64_t param,
+                       unsigned c, void *packed_dev)
+{
+    int rc = check_width(c);
+    if (rc) return rc;
+    if (!packed_dev) return fail(MI355_E_INVALID, "packed_dev is null");
+    if (((uintptr_t)packed_dev & 3) != 0) return fail(MI355_E_INVALID, "packed_dev must be 4-byte aligned");
+    if ((src == kSrcU16 || src == kSrcU32) && !values_dev && n) return fail(MI355_E_INVALID, "values_dev is null");
+    if (src == kSrcMod && param == 0) return fail(MI355_E_INVALID, "modulus 0");
+    PackArgs a;
+    a.values = values_dev;
+    a.n = n;
+    a.first_row = first_row;
+    a.param = param;
+    a.out = (uint32_t *)packed_dev;
+    a.out_dwords = mi355_compressed_buffer_size(c, n) / 4; // payload + pad, whole dwords
+    a.c = c;
+    uint64_t blocks = (a.out_dwords + 255) / 256;
+    uint64_t cap = (uint64_t)ctx->num_cus * 8;
+    unsigned grid = (unsigned)(blocks < cap ? (blocks ? blocks : 1) : cap);
+    switch (src) {
+    case kSrcU16: hipLaunchKernelGGL(pack_kernel<kSrcU16>, dim3(grid), dim3(256), 0, ctx->stream, a); break;
+    case kSrcU32: hipLaunchKernelGGL(pack_kernel<kSrcU32>, dim3(grid), dim3(256), 0, ctx->stream, a); break;
+    case kSrcMod: hipLaunchKernelGGL(pack_kernel<kSrcMod>, dim3(grid), dim3(256), 0, ctx->stream, a); break;
+    case kSrcSplitmix: hipLaunchKernelGGL(pack_kernel<kSrcSplitmix>, dim3(grid), dim3(256), 0, ctx->stream, a); break;
+    case kSrcIndex: hipLaunchKernelGGL(pack_kernel<kSrcIndex>, dim3(grid), dim3(256), 0, ctx->stream, a); break;
+    default: return fail(MI355_E_INVALID, "unknown pack source %d", src);
+    }
+    HIP_TRY(hipGetLastError());
+    // the trailing (compressed_buffer_size % 4) pad bytes, if any
+    size_t total = mi355_compressed_buffer_size(c, n);
+    if (total % 4) HIP_TRY(hipMemsetAsync((uint8_t *)packed_dev + total / 4 * 4, 0, total % 4, ctx->stream));
+    return MI355_OK;
+}
+
+int mi355_pack_u16_dev(mi355_ctx *ctx, const uint16_t *values_dev, uint64_t n, unsigned c, void *packed_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    return pack_launch(ctx, kSrcU16, values_dev, n, 0, 0, c, packed_dev);
+}
+int mi355_pack_u32_dev(mi355_ctx *ctx, const uint32_t *values_dev, uint64_t n, unsigned c, void *packed_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    return pack_launch(ctx, kSrcU32, values_dev, n, 0, 0, c, packed_dev);
+}
+int mi355_generate_dev(mi355_ctx *ctx, int kind, uint64_t first_row, uint64_t n, unsigned c, uint64_t param,
+                       void *packed_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    int src = kind == MI355_GEN_MOD ? kSrcMod : kind == MI355_GEN_SPLITMIX ? kSrcSplitmix : kind == MI355_GEN_INDEX ? kSrcIndex : -1;
+    if (src < 0) return fail(MI355_E_INVALID, "unknown generator kind %d", kind);
+    return pack_launch(ctx, src, nullptr, n, first_row, param, c, packed_dev);
+}
+
+static int pack_host(mi355_ctx *ctx, int src, const void *values, size_t elem, uint64_t n, unsigned c, void *packed_host)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if ((rc = check_width(c))) return rc;
+    if (!packed_host || (!values && n)) return fail(MI355_E_INVALID, "null pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf dv, dp;
+    size_t pbytes = mi355_compressed_buffer_size(c, n);
+    HIP_TRY(hipMalloc(&dv.p, n * elem + 16));
+    HIP_TRY(hipMalloc(&dp.p, pbytes + 16));
+    HIP_TRY(hipMemcpyAsync(dv.p, values, n * elem, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pack_launch(ctx, src, dv.p, n, 0, 0, c, dp.p))) return rc;
+    HIP_TRY(hipMemcpyAsync(packed_host, dp.p, pbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+int mi355_pack_u16(mi355_ctx *ctx, const uint16_t *values, uint64_t n, unsigned c, void *packed_host)
+{
+    return pack_host(ctx, kSrcU16, values, 2, n, c, packed_host);
+}
+int mi355_pack_u32(mi355_ctx *ctx, const uint32_t *values, uint64_t n, unsigned c, void *packed_host)
+{
+    return pack_host(ctx, kSrcU32, values, 4, n, c, packed_host);
+}
+
+/* ---- decompress ---- */
+int mi355_decompress_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int32_t *out_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if ((rc = check_width(c))) return rc;
+    if (n == 0) return MI355_OK;
+    if (!packed_dev || !out_dev) return fail(MI355_E_INVALID, "null device pointer");
+    if (((uintptr_t)packed_dev & 15) != 0) return fail(MI355_E_INVALID, "packed_dev must be 16-byte aligned");
+    if (((uintptr_t)out_dev & 15) != 0) return fail(MI355_E_INVALID, "out_dev must be 16-byte aligned");
+    LaunchReq r{};
+    r.op = kOpDecompress;
+    r.c = c;
+    r.decomp.packed = (const uint8_t *)packed_dev;
+    r.decomp.n = n;
+    r.decomp.out = out_dev;
+    return launch(ctx, r);
+}
+
+/* ---- scans (device pointers) ---- */
+static int scan_common_dev(mi355_ctx *ctx, int op, const void *packed_dev, uint64_t n, unsigned c, uint32_t k0,
+                           uint32_t k1, void *bitmap_dev, uint64_t *hits_dev)
+{
+    int rc = check_width(c);
+    if (rc) return rc;
+    if (hits_dev) HIP_TRY(hipMemsetAsync(hits_dev, 0, sizeof(uint64_t), ctx->stream));
+    if (n == 0) return MI355_OK;
+    if (!packed_dev || !bitmap_dev) return fail(MI355_E_INVALID, "null device pointer");
+    if (((uintptr_t)packed_dev & 15) != 0) return fail(MI355_E_INVALID, "packed_dev must be 16-byte aligned");
+    if (((uintptr_t)bitmap_dev & 15) != 0) return fail(MI355_E_INVALID, "bitmap_dev must be 16-byte aligned");
+    LaunchReq r{};
+    r.op = op;
+    r.c = c;
+    r.scan.packed = (const uint8_t *)packed_dev;
+    r.scan.n = n;
+    r.scan.out = (uint8_t *)bitmap_dev;
+    r.scan.hits = (unsigned long long *)hits_dev;
+    r.scan.key[0] = k0;
+    r.scan.key[1] = k1;
+    r.scan.nkeys = 1;
+    return launch(ctx, r);
+}
+
+int mi355_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int32_t key, void *bitmap_dev,
+                      uint64_t *hits_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    return scan_common_dev(ctx, kOpScanEq, packed_dev, n, c, (uint32_t)key, 0, bitmap_dev, hits_dev);
+}
+
+int mi355_scan_range_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, uint32_t lo, uint32_t hi,
+                         void *bitmap_dev, uint64_t *hits_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if (lo > hi) {
+        // empty range: all-zero bitmap, zero hits
+        if ((rc = check_width(c))) return rc;
+        if (hits_dev) HIP_TRY(hipMemsetAsync(hits_dev, 0, sizeof(uint64_t), ctx->stream));
+        if (n && !bitmap_dev) return fail(MI355_E_INVALID, "null device pointer");
+        if (n) HIP_TRY(hipMemsetAsync(bitmap_dev, 0, bitmap_bytes(n), ctx->stream));
+        return MI355_OK;
+    }
+    return scan_common_dev(ctx, kOpScanRange, packed_dev, n, c, lo, hi - lo, bitmap_dev, hits_dev);
+}
+
+int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const int32_t *keys_host,
+                             unsigned P, int layout, void *out_dev, uint64_t stride_bytes, uint64_t *hits_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if ((rc = check_width(c))) return rc;
+    if (P < 1 || P > kMaxKeys) return fail(MI355_E_INVALID, "P=%u outside 1..%u", P, kMaxKeys);
+    if (!keys_host) return fail(MI355_E_INVALID, "keys is null");
+    if (layout != MI355_LAYOUT_PER_PREDICATE && layout != MI355_LAYOUT_LINEAR)
+        return fail(MI355_E_INVALID, "unknown layout %d", layout);
+    if (hits_dev) HIP_TRY(hipMemsetAsync(hits_dev, 0, P * sizeof(uint64_t), ctx->stream));
+    if (n == 0) return MI355_OK;
+    if (!packed_dev || !out_dev) return fail(MI355_E_INVALID, "null device pointer");
+    if (((uintptr_t)packed_dev & 15) != 0) return fail(MI355_E_INVALID, "packed_dev must be 16-byte aligned");
+    if (layout == MI355_LAYOUT_PER_PREDICATE) {
+        if (((uintptr_t)out_dev & 15) != 0 || (stride_bytes & 15) != 0)
+            return fail(MI355_E_INVALID, "out_dev and stride_bytes must be multiples of 16");
+        if (stride_bytes < bitmap_bytes(n)) return fail(MI355_E_INVALID, "stride_bytes smaller than ceil(n/8)");
+    }
+    LaunchReq r{};
+    r.op = kOpSharedScan;
+    r.c = c;
+    r.scan.packed = (const uint8_t *)packed_dev;
+    r.scan.n = n;
+    r.scan.out = (uint8_t *)out_dev;
+    r.scan.out_stride = stride_bytes;
+    r.scan.hits = (unsigned long long *)hits_dev;
+    r.scan.nkeys = P;
+    r.scan.layout = (uint32_t)layout;
+    if (P <= (unsigned)kMaxKeysPerPass) {
+        for (unsigned q = 0; q < (unsigned)kMaxKeysPerPass; q++) r.scan.key[q] = (uint32_t)keys_host[q < P ? q : P - 1];
+    } else {
+        // keys travel through device memory, padded to a multiple of 8 with copies of the last key
+        std::vector<int32_t> padded((P + 7) / 8 * 8, keys_host[P - 1]);
+        memcpy(padded.data(), keys_host, P * sizeof(int32_t));
+        HIP_TRY(hipMemcpyAsync(ctx->keys_scratch, padded.data(), padded.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream)); // `padded` dies at scope exit
+        r.scan.keys_dev = ctx->keys_scratch;
+    }
+    return launch(ctx, r);
+}
+
+/* ---- host-pointer (copying, synchronous) flavours: the drop-in path ---- */
+int mi355_decompress(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, int32_t *out_host)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if ((rc = check_width(c))) return rc;
+    if (n == 0) return MI355_OK;
+    if (!packed_host || !out_host) return fail(MI355_E_INVALID, "null pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf dp, dout;
+    size_t pbytes = mi355_compressed_buffer_size(c, n);
+    HIP_TRY(hipMalloc(&dp.p, pbytes));
+    HIP_TRY(hipMalloc(&dout.p, n * 4));
+    HIP_TRY(hipMemcpyAsync(dp.p, packed_host, pbytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = mi355_decompress_dev(ctx, dp.p, n, c, (int32_t *)dout.p))) return rc;
+    HIP_TRY(hipMemcpyAsync(out_host, dout.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+
+static int scan_host(mi355_ctx *ctx, int op, const void *packed_host, uint64_t n, unsigned c, uint32_t k0, uint32_t k1,
+                     uint8_t *bitmap_host, uint64_t *hits)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if ((rc = check_width(c))) return rc;
+    if (hits) *hits = 0;
+    if (n == 0) return MI355_OK;
+    if (!packed_host || !bitmap_host) return fail(MI355_E_INVALID, "null pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf dp, db;
+    size_t pbytes = mi355_compressed_buffer_size(c, n);
+    HIP_TRY(hipMalloc(&dp.p, pbytes));
+    HIP_TRY(hipMalloc(&db.p, bitmap_bytes(n) + 16));
+    HIP_TRY(hipMemcpyAsync(dp.p, packed_host, pbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (op == kOpScanRange)
+        rc = mi355_scan_range_dev(ctx, dp.p, n, c, k0, k1, db.p, (uint64_t *)ctx->hits_scratch);
+    else
+        rc = mi355_scan_eq_dev(ctx, dp.p, n, c, (int32_t)k0, db.p, (uint64_t *)ctx->hits_scratch);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(bitmap_host, db.p, bitmap_bytes(n), hipMemcpyDeviceToHost, ctx->stream));
+    uint64_t h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, ctx->hits_scratch, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (hits) *hits = h;
+    return MI355_OK;
+}
+
+int mi355_scan_eq(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, int32_t key, uint8_t *bitmap_host,
+                  uint64_t *hits)
+{
+    return scan_host(ctx, kOpScanEq, packed_host, n, c, (uint32_t)key, 0, bitmap_host, hits);
+}
+int mi355_scan_range(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, uint32_t lo, uint32_t hi,
+                     uint8_t *bitmap_host, uint64_t *hits)
+{
+    return scan_host(ctx, kOpScanRange, packed_host, n, c, lo, hi, bitmap_host, hits);
+}
+
+static int shared_host(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, const int32_t *keys, unsigned P,
+                       int layout, uint8_t *const *outputs, uint8_t *linear_out, uint64_t *hits)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if ((rc = check_width(c))) return rc;
+    if (P < 1 || P > kMaxKeys) return fail(MI355_E_INVALID, "P=%u outside 1..%u", P, kMaxKeys);
+    if (!keys) return fail(MI355_E_INVALID, "keys is null");
+    if (hits) memset(hits, 0, P * sizeof(uint64_t));
+    if (n == 0) return MI355_OK;
+    if (!packed_host || (layout == MI355_LAYOUT_PER_PREDICATE ? !outputs : !linear_out))
+        return fail(MI355_E_INVALID, "null pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nb = bitmap_bytes(n);
+    const size_t stride = (nb + 15) / 16 * 16;
+    DevBuf dp, dout;
+    size_t pbytes = mi355_compressed_buffer_size(c, n);
+    HIP_TRY(hipMalloc(&dp.p, pbytes));
+    HIP_TRY(hipMalloc(&dout.p, (layout == MI355_LAYOUT_PER_PREDICATE ? stride : nb) * P + 16));
+    HIP_TRY(hipMemcpyAsync(dp.p, packed_host, pbytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = mi355_shared_scan_eq_dev(ctx, dp.p, n, c, keys, P, layout, dout.p, stride, (uint64_t *)ctx->hits_scratch)))
+        return rc;
+    if (layout == MI355_LAYOUT_PER_PREDICATE) {
+        for (unsigned k = 0; k < P; k++) {
+            if (!outputs[k]) return fail(MI355_E_INVALID, "outputs[%u] is null", k);
+            HIP_TRY(hipMemcpyAsync(outputs[k], (uint8_t *)dout.p + k * stride, nb, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    } else {
+        HIP_TRY(hipMemcpyAsync(linear_out, dout.p, nb * P, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    std::vector<uint64_t> h(P);
+    HIP_TRY(hipMemcpyAsync(h.data(), ctx->hits_scratch, P * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (hits) memcpy(hits, h.data(), P * sizeof(uint64_t));
+    return MI355_OK;
+}
+
+int mi355_shared_scan_eq(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, const int32_t *keys,
+                         unsigned P, uint8_t *const *outputs, uint64_t *hits)
+{
+    return shared_host(ctx, packed_host, n, c, keys, P, MI355_LAYOUT_PER_PREDICATE, outputs, nullptr, hits);
+}
+int mi355_shared_scan_eq_linear(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, const int32_t *keys,
+                                unsigned P, uint8_t *output, uint64_t *hits)
+{
+    return shared_host(ctx, packed_host, n, c, keys, P, MI355_LAYOUT_LINEAR, nullptr, output, hits);
+}
+
+/* ---- introspection ---- */
+const char *mi355_kernel_name(const char *op, unsigned c)
+{
+    static thread_local char buf[96];
+    if (!op || c < 1 || c > 32) return nullptr;
+    if (!strcmp(op, "scan_eq"))
+        snprintf(buf, sizeof buf, "mi355::scan_kernel<%u, 0, ", c);
+    else if (!strcmp(op, "scan_range"))
+        snprintf(buf, sizeof buf, "mi355::scan_kernel<%u, 1, ", c);
+    else if (!strcmp(op, "shared_scan"))
+        snprintf(buf, sizeof buf, "mi355::scan_kernel<%u, 2, ", c);
+    else if (!strcmp(op, "decompress"))
+        snprintf(buf, sizeof buf, "mi355::decompress_kernel<%u, ", c);
+    else if (!strcmp(op, "pack"))
+        snprintf(buf, sizeof buf, "mi355::pack_kernel<");
+    else
+        return nullptr;
+    return buf;
+}
+
+uint64_t mi355_tile_values(unsigned c)
+{
+    if (c < 1 || c > 32) return 0;
+    return c <= 16 ? 8192 : 4096;
+}
+
+} // extern "C"

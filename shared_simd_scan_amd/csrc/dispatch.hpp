@@ -1,0 +1,44 @@
+// dispatch.hpp -- host-side launch request shared by capi.hip and the width-group translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace mi355 {
+
+enum Op { kOpScanEq = 0, kOpScanRange = 1, kOpSharedScan = 2, kOpDecompress = 3 };
+
+struct LaunchReq {
+    int op;
+    unsigned c;
+    hipStream_t stream;
+    int num_cus;
+    int max_blocks_per_cu; // 0 = what the occupancy query allows
+    int dma_aux;           // cache policy of the HBM->LDS loads: 0 default, 2 nt
+    ScanArgs scan;
+    DecompArgs decomp;
+};
+
+// Persistent grid: at most (resident blocks per CU) x (CUs) blocks of 4 waves; each wave strides
+// over the wave tiles.  Small inputs get one wave per tile.
+inline unsigned grid_for(uint64_t ntiles, int blocks_per_cu, int num_cus)
+{
+    uint64_t want = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    uint64_t cap = (uint64_t)blocks_per_cu * (uint64_t)num_cus;
+    if (want < 1) want = 1;
+    return (unsigned)(want < cap ? want : cap);
+}
+
+constexpr int kNumGroups = 8; // widths 1..32, 4 per group
+hipError_t launch_group_0(const LaunchReq &);
+hipError_t launch_group_1(const LaunchReq &);
+hipError_t launch_group_2(const LaunchReq &);
+hipError_t launch_group_3(const LaunchReq &);
+hipError_t launch_group_4(const LaunchReq &);
+hipError_t launch_group_5(const LaunchReq &);
+hipError_t launch_group_6(const LaunchReq &);
+hipError_t launch_group_7(const LaunchReq &);
+
+} // namespace mi355

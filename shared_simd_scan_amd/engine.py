@@ -1,0 +1,174 @@
+"""ScanEngine -- Python face of the C ABI for device-resident columns.
+
+torch is plumbing here: it owns device memory (uint8 / int32 tensors), the HIP stream the kernels are
+enqueued on, and (in sharded.py) the RCCL process group.  Every operation is one call into
+libmi355scan.so; nothing is computed in Python and nothing falls back to the CPU.
+
+Names follow the reference's surface (src/simd_scan.hpp): compress / decompress / scan / shared_scan.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import check, lib
+
+
+def compressed_buffer_size(c: int, n: int) -> int:
+    """src/simd_scan.hpp:20-26"""
+    return lib().mi355_compressed_buffer_size(c, n)
+
+
+def decompression_output_buffer_size(n: int) -> int:
+    """src/simd_scan.hpp:28-33"""
+    return lib().mi355_decompression_output_buffer_size(n)
+
+
+def scan_output_buffer_size(n: int) -> int:
+    """src/simd_scan.hpp:35-40"""
+    return lib().mi355_scan_output_buffer_size(n)
+
+
+def tile_values(c: int) -> int:
+    return int(lib().mi355_tile_values(c))
+
+
+def kernel_name(op: str, c: int) -> str:
+    s = lib().mi355_kernel_name(op.encode(), c)
+    if s is None:
+        raise ValueError(op)
+    return s.decode()
+
+
+class PackedColumn:
+    """A bit-packed column resident in HBM: `n` values of `c` bits, reference stream format."""
+
+    def __init__(self, data: torch.Tensor, n: int, c: int):
+        assert data.dtype == torch.uint8 and data.is_cuda
+        self.data, self.n, self.c = data, int(n), int(c)
+
+    @property
+    def payload_bytes(self) -> int:
+        return (self.n * self.c + 7) // 8
+
+
+class ScanEngine:
+    def __init__(self, device: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None):
+        if not torch.cuda.is_available():
+            raise _capi.Mi355Error("no GPU visible: shared_simd_scan_amd has no CPU fallback")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        with torch.cuda.device(self.device):
+            self.stream = stream if stream is not None else torch.cuda.current_stream()
+        self._ctx = C.c_void_p()
+        check(lib().mi355_ctx_create(self.device, C.c_void_p(self.stream.cuda_stream), C.byref(self._ctx)))
+        self._dev = torch.device("cuda", self.device)
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            lib().mi355_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name: str, value: int) -> None:
+        check(lib().mi355_ctx_set_option(self._ctx, name.encode(), int(value)))
+
+    def synchronize(self) -> None:
+        check(lib().mi355_ctx_synchronize(self._ctx))
+
+    # ---- allocation -----------------------------------------------------------------------
+    def _empty(self, nbytes: int, dtype=torch.uint8) -> torch.Tensor:
+        return torch.empty(nbytes, dtype=dtype, device=self._dev)
+
+    def alloc_packed(self, n: int, c: int) -> PackedColumn:
+        return PackedColumn(self._empty(compressed_buffer_size(c, n)), n, c)
+
+    # ---- compression (src/simd_scan_compression.cpp:53-104) ----------------------------------
+    def compress(self, values: torch.Tensor, c: int) -> PackedColumn:
+        """values: uint16 / int32 / uint32-as-int32 tensor on this device -> packed column."""
+        values = values.to(self._dev).contiguous()
+        n = values.numel()
+        col = self.alloc_packed(n, c)
+        if values.dtype in (torch.uint16, torch.int16):
+            check(lib().mi355_pack_u16_dev(self._ctx, values.data_ptr(), n, c, col.data.data_ptr()))
+        elif values.dtype in (torch.int32, torch.uint32):
+            check(lib().mi355_pack_u32_dev(self._ctx, values.data_ptr(), n, c, col.data.data_ptr()))
+        else:
+            raise TypeError(f"values dtype {values.dtype}: need a 16- or 32-bit integer tensor")
+        return col
+
+    def generate(self, kind: str, n: int, c: int, param: int = 0, first_row: int = 0) -> PackedColumn:
+        """Synthesise a packed column on the device: 'mod' | 'splitmix' | 'index' (SURVEY 8d)."""
+        code = {"mod": _capi.GEN_MOD, "splitmix": _capi.GEN_SPLITMIX, "index": _capi.GEN_INDEX}[kind]
+        col = self.alloc_packed(n, c)
+        check(lib().mi355_generate_dev(self._ctx, code, first_row, n, c, param, col.data.data_ptr()))
+        return col
+
+    # ---- decompression (src/simd_scan_decompression.cpp) --------------------------------------
+    def decompress(self, col: PackedColumn, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = self._empty(col.n, torch.int32)
+        assert out.dtype == torch.int32 and out.numel() >= col.n
+        check(lib().mi355_decompress_dev(self._ctx, col.data.data_ptr(), col.n, col.c, out.data_ptr()))
+        return out
+
+    # ---- scans (src/simd_scan.cpp) -------------------------------------------------------------
+    def alloc_bitmap(self, n: int) -> torch.Tensor:
+        return self._empty((n + 7) // 8)
+
+    def scan(self, key: int, col: PackedColumn, bitmap: Optional[torch.Tensor] = None,
+             hits: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """value == key -> (bitmap uint8[ceil(n/8)], hits int64[1]); asynchronous on the stream."""
+        if bitmap is None:
+            bitmap = self.alloc_bitmap(col.n)
+        if hits is None:
+            hits = torch.empty(1, dtype=torch.int64, device=self._dev)
+        key32 = int(np.int32(np.uint32(int(key) & 0xFFFFFFFF)))
+        check(lib().mi355_scan_eq_dev(self._ctx, col.data.data_ptr(), col.n, col.c, key32, bitmap.data_ptr(),
+                                      hits.data_ptr()))
+        return bitmap, hits
+
+    def scan_range(self, lo: int, hi: int, col: PackedColumn, bitmap: Optional[torch.Tensor] = None,
+                   hits: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """lo <= value <= hi (src/simd_scan.hpp:76-84)."""
+        if bitmap is None:
+            bitmap = self.alloc_bitmap(col.n)
+        if hits is None:
+            hits = torch.empty(1, dtype=torch.int64, device=self._dev)
+        check(lib().mi355_scan_range_dev(self._ctx, col.data.data_ptr(), col.n, col.c, lo, hi, bitmap.data_ptr(),
+                                         hits.data_ptr()))
+        return bitmap, hits
+
+    # ---- shared scans (src/simd_scan_shared.cpp, src/simd_scan_shared_linear.cpp) -----------------
+    def shared_scan(self, keys: Sequence[int], col: PackedColumn, layout: str = "per_predicate",
+                    out: Optional[torch.Tensor] = None, hits: Optional[torch.Tensor] = None):
+        """per_predicate -> uint8[P, stride] (row k = bitmap of keys[k], stride = ceil(n/8) rounded up to 16);
+        linear -> uint8[ceil(n/8) * P] with the byte of 8-value group g and key k at g*P + k."""
+        k = np.ascontiguousarray(np.asarray(keys, dtype=np.int64).astype(np.int32))
+        P = int(k.shape[0])
+        nb = (col.n + 7) // 8
+        if hits is None:
+            hits = torch.empty(P, dtype=torch.int64, device=self._dev)
+        if layout == "per_predicate":
+            stride = (nb + 15) // 16 * 16
+            if out is None:
+                out = torch.empty((P, stride), dtype=torch.uint8, device=self._dev)
+            code = _capi.LAYOUT_PER_PREDICATE
+        elif layout == "linear":
+            stride = 0
+            if out is None:
+                out = self._empty(nb * P)
+            code = _capi.LAYOUT_LINEAR
+        else:
+            raise ValueError(layout)
+        check(lib().mi355_shared_scan_eq_dev(self._ctx, col.data.data_ptr(), col.n, col.c, k.ctypes.data, P, code,
+                                             out.data_ptr(), stride, hits.data_ptr()))
+        return out, hits

@@ -1,0 +1,371 @@
+"""GPU (-m gpu): the HIP path through the C ABI vs the oracle and vs the reference's golden vectors.
+
+Bit-exact everywhere: this is integer / bit work, there is no tolerance.  Parity is defined on bits
+[0, n) plus the canonical zero tail (DESIGN.md "tail rule"); hits = popcount over [0, n).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_SIZES, GOLDEN_WIDTHS
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(buf, n):
+    return np.unpackbits(np.ascontiguousarray(buf, dtype=np.uint8), bitorder="little")[:n]
+
+
+def vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from shared_simd_scan_amd import lib
+
+    return lib()
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    from shared_simd_scan_amd import ScanEngine
+
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    return ScanEngine()
+
+
+def ok(L, rc):
+    assert rc == 0, L.mi355_last_error()
+
+
+# ------------------------------------------------------------------------------------------------
+# host-pointer C ABI (the drop-in flavour) against the reference's golden vectors
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("w", GOLDEN_WIDTHS)
+@pytest.mark.parametrize("n", GOLDEN_SIZES)
+def test_golden_pack_decompress(L, golden, w, n):
+    g = golden[w]
+    values, ref_packed = g[f"n{n}_values"], g[f"n{n}_packed"]
+    packed = np.full(L.mi355_compressed_buffer_size(w, n), 0xAA, dtype=np.uint8)
+    if w <= 16:
+        v16 = np.ascontiguousarray(values.astype(np.uint16))
+        ok(L, L.mi355_pack_u16(None, vp(v16), n, w, vp(packed)))
+    else:
+        v32 = np.ascontiguousarray(values.astype(np.uint32))
+        ok(L, L.mi355_pack_u32(None, vp(v32), n, w, vp(packed)))
+    assert np.array_equal(packed, ref_packed)  # byte-identical incl. the zero pad
+    out = np.full(n, -1, dtype=np.int32)
+    ok(L, L.mi355_decompress(None, vp(ref_packed), n, w, vp(out)))
+    assert np.array_equal(out, g[f"n{n}_decomp"])
+
+
+@pytest.mark.parametrize("w", GOLDEN_WIDTHS)
+@pytest.mark.parametrize("n", GOLDEN_SIZES)
+def test_golden_scan_eq(L, golden, w, n):
+    g = golden[w]
+    packed = np.ascontiguousarray(g[f"n{n}_packed"])
+    sobs = L.mi355_scan_output_buffer_size(n)
+    nb = (n + 7) // 8
+    for key, ref_buf, ref_hits in zip(g[f"n{n}_keys"], g[f"n{n}_scan128"], g[f"n{n}_scan128_hits"]):
+        out = np.zeros(sobs, dtype=np.uint8)
+        hits = C.c_uint64(123)
+        ok(L, L.mi355_scan_eq(None, vp(packed), n, w, int(key), vp(out), C.byref(hits)))
+        assert np.array_equal(bits(out, n), bits(ref_buf, n))
+        assert not out[nb:].any()  # untouched padding stays 0 (SURVEY 8c hazard 4)
+        if key != 0:
+            assert np.array_equal(out, ref_buf)  # whole padded buffer identical to scan_128's
+            assert hits.value == ref_hits
+        else:
+            assert hits.value == bits(ref_buf, n).sum()
+            assert bits(out, nb * 8)[n:].sum() == 0
+
+
+@pytest.mark.parametrize("w", GOLDEN_WIDTHS)
+@pytest.mark.parametrize("n", GOLDEN_SIZES)
+@pytest.mark.parametrize("P", [1, 3, 8])
+def test_golden_shared_scan(L, golden, w, n, P):
+    g = golden[w]
+    packed = np.ascontiguousarray(g[f"n{n}_packed"])
+    keys = np.ascontiguousarray(g[f"n{n}_shared_keys_P{P}"].astype(np.int32))
+    ref_std, ref_lin = g[f"n{n}_shared_std_P{P}"], g[f"n{n}_linear_std_P{P}"]
+    sobs = L.mi355_scan_output_buffer_size(n)
+    nb, full = (n + 7) // 8, n // 8
+    outs = [np.zeros(sobs, dtype=np.uint8) for _ in range(P)]
+    ptrs = (C.c_void_p * P)(*[o.ctypes.data for o in outs])
+    hits = np.zeros(P, dtype=np.uint64)
+    ok(L, L.mi355_shared_scan_eq(None, vp(packed), n, w, vp(keys), P, ptrs, vp(hits)))
+    lin = np.zeros(P * sobs, dtype=np.uint8)
+    hits2 = np.zeros(P, dtype=np.uint64)
+    ok(L, L.mi355_shared_scan_eq_linear(None, vp(packed), n, w, vp(keys), P, vp(lin), vp(hits2)))
+    assert np.array_equal(hits, hits2)
+    for k in range(P):
+        assert np.array_equal(bits(outs[k], n), bits(ref_std[k], n))
+        assert hits[k] == bits(ref_std[k], n).sum()
+        assert not outs[k][nb:].any()
+    assert np.array_equal(lin[: full * P], ref_lin[: full * P])
+    for k in range(P):
+        assert np.array_equal(bits(lin[k::P][:nb], n), bits(ref_lin[k::P][:nb], n))
+    assert not lin[nb * P:].any()
+
+
+def test_kat_reference_unit_tests(L, golden):
+    """test/simd_scan_tests.cpp restated against the C ABI."""
+    kat = np.array([1, 2, 3, 3, 2, 1, 1, 2, 3, 1, 2, 3], dtype=np.uint16)
+    packed = np.zeros(L.mi355_compressed_buffer_size(9, 12), dtype=np.uint8)
+    ok(L, L.mi355_pack_u16(None, vp(kat), 12, 9, vp(packed)))
+    sobs = L.mi355_scan_output_buffer_size(12)
+    # "SIMD Scan" (:45-82)
+    out = np.zeros(sobs, dtype=np.uint8)
+    hits = C.c_uint64()
+    ok(L, L.mi355_scan_eq(None, vp(packed), 12, 9, 3, vp(out), C.byref(hits)))
+    assert hits.value == 4
+    assert bits(out, 12).tolist() == (kat == 3).astype(int).tolist()
+    # "Simple Shared SIMD Scan" (:108-150): outputs1 == compare_output, whole padded vector
+    keys1 = np.array([1], dtype=np.int32)
+    lin1 = np.zeros(sobs, dtype=np.uint8)
+    ok(L, L.mi355_shared_scan_eq_linear(None, vp(packed), 12, 9, vp(keys1), 1, vp(lin1), None))
+    cmp1 = np.zeros(sobs, dtype=np.uint8)
+    ok(L, L.mi355_scan_eq(None, vp(packed), 12, 9, 1, vp(cmp1), C.byref(hits)))
+    assert hits.value == 4 and np.array_equal(lin1, cmp1)
+    assert np.array_equal(lin1, golden[9]["n12_linear_simple_P1"])
+    keys2 = np.array([2, 3], dtype=np.int32)
+    lin2 = np.zeros(2 * sobs, dtype=np.uint8)
+    ok(L, L.mi355_shared_scan_eq_linear(None, vp(packed), 12, 9, vp(keys2), 2, vp(lin2), None))
+    assert np.array_equal(lin2, golden[9]["n12_linear_simple_P2"])
+    # "Compress and decompress" (:6-43)
+    n = (1 << 9) - 3
+    ident = np.arange(n, dtype=np.uint16)
+    packed = np.zeros(L.mi355_compressed_buffer_size(9, n), dtype=np.uint8)
+    ok(L, L.mi355_pack_u16(None, vp(ident), n, 9, vp(packed)))
+    dec = np.zeros(n, dtype=np.int32)
+    ok(L, L.mi355_decompress(None, vp(packed), n, 9, vp(dec)))
+    assert np.array_equal(dec, ident.astype(np.int32))
+
+
+def test_invalid_arguments(L):
+    buf = np.zeros(600, dtype=np.uint8)
+    hits = C.c_uint64()
+    assert L.mi355_scan_eq(None, vp(buf), 12, 0, 3, vp(buf), C.byref(hits)) == -1
+    assert L.mi355_scan_eq(None, vp(buf), 12, 33, 3, vp(buf), C.byref(hits)) == -1
+    assert L.mi355_scan_eq(None, None, 12, 9, 3, vp(buf), C.byref(hits)) == -1
+    keys = np.zeros(4, dtype=np.int32)
+    assert L.mi355_shared_scan_eq_linear(None, vp(buf), 12, 9, vp(keys), 0, vp(buf), None) == -1
+    assert L.mi355_shared_scan_eq_linear(None, vp(buf), 12, 9, vp(keys), 1025, vp(buf), None) == -1
+    # n == 0 is fine and writes nothing
+    out = np.full(40, 7, dtype=np.uint8)
+    ok(L, L.mi355_scan_eq(None, vp(buf), 0, 9, 3, vp(out), C.byref(hits)))
+    assert hits.value == 0 and (out == 7).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# device-resident path (ScanEngine) vs the oracle on seeded random columns
+# ------------------------------------------------------------------------------------------------
+
+def make_column(O, eng, n, c, seed):
+    import torch
+
+    rng = np.random.default_rng(seed)
+    vals = rng.integers(0, 1 << c, size=n, dtype=np.uint64).astype(np.uint32)
+    col = eng.compress(torch.from_numpy(vals.view(np.int32)).cuda(), c)
+    return vals, col
+
+
+@pytest.mark.parametrize("c", list(range(1, 33)))
+def test_all_widths_vs_oracle(O, eng, c):
+    """every width 1..32, n chosen to leave a ragged tail in the last tile"""
+    import torch
+
+    n = 3 * 8192 + 1237
+    vals, col = make_column(O, eng, n, c, 100 + c)
+    packed_host = col.data.cpu().numpy()
+    assert np.array_equal(packed_host, O.pack(vals, c))  # device packer == reference format
+    dec = eng.decompress(col)
+    assert np.array_equal(dec.cpu().numpy().view(np.uint32), vals)
+    for key in (int(vals[17]), 0, (1 << c) - 1):
+        bm, hits = eng.scan(key, col)
+        obm, ohits = O.scan_eq(packed_host, n, c, key if key < 2 ** 31 else key - 2 ** 32)
+        assert np.array_equal(bm.cpu().numpy(), obm), (c, key)
+        assert int(hits.item()) == ohits
+    lo, hi = (1 << c) // 4, (1 << c) // 2
+    bm, hits = eng.scan_range(lo, hi, col)
+    obm, ohits = O.scan_range(packed_host, n, c, lo, hi)
+    assert np.array_equal(bm.cpu().numpy(), obm) and int(hits.item()) == ohits
+    keys = [int(vals[(31 * k + 5) % n]) for k in range(8)]
+    keys = [k if k < 2 ** 31 else k - 2 ** 32 for k in keys]
+    out, hits = eng.shared_scan(keys, col)
+    oout, ohits = O.shared_scan_eq(packed_host, n, c, keys)
+    nb = (n + 7) // 8
+    assert np.array_equal(out.cpu().numpy()[:, :nb], oout)
+    assert np.array_equal(hits.cpu().numpy().astype(np.uint64), ohits)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 16384, 100003])
+@pytest.mark.parametrize("c", [9, 12, 21])
+def test_ragged_sizes(O, eng, n, c):
+    vals, col = make_column(O, eng, n, c, 7 * n + c)
+    packed_host = col.data.cpu().numpy()
+    nb = (n + 7) // 8
+    key = int(vals[n // 2])
+    # sentinel-filled outputs: exactly ceil(n/8) bytes / n ints may be written
+    import torch
+
+    bm = torch.full((nb + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+    _, hits = eng.scan(key, col, bitmap=bm)
+    obm, ohits = O.scan_eq(packed_host, n, c, key)
+    host = bm.cpu().numpy()
+    assert np.array_equal(host[:nb], obm) and (host[nb:] == 0x5A).all()
+    assert int(hits.item()) == ohits
+    dec = torch.full((n + 64,), -7, dtype=torch.int32, device="cuda")
+    eng.decompress(col, out=dec)
+    host = dec.cpu().numpy()
+    assert np.array_equal(host[:n].view(np.uint32), vals) and (host[n:] == -7).all()
+    # key 0 on a ragged tail: pad values decode as 0 in the reference; canonical tail is zero
+    bm0, hits0 = eng.scan(0, col)
+    obm0, oh0 = O.scan_eq(packed_host, n, c, 0)
+    assert np.array_equal(bm0.cpu().numpy(), obm0) and int(hits0.item()) == oh0 == int((vals == 0).sum())
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 5, 8, 9, 16, 37, 128])
+@pytest.mark.parametrize("layout", ["per_predicate", "linear"])
+def test_shared_scan_predicate_counts(O, eng, P, layout):
+    n, c = 2 * 8192 + 77, 9
+    vals, col = make_column(O, eng, n, c, 500 + P)
+    packed_host = col.data.cpu().numpy()
+    keys = [int(v) for v in np.random.default_rng(P).integers(0, 1 << c, size=P)]
+    keys[0] = 0  # the reference's own shared-scan bench uses keys 0..P-1 (src/benchmark.cpp:205-209)
+    out, hits = eng.shared_scan(keys, col, layout=layout)
+    oout, ohits = O.shared_scan_eq(packed_host, n, c, keys, layout)
+    nb = (n + 7) // 8
+    got = out.cpu().numpy()
+    if layout == "per_predicate":
+        got = got[:, :nb]
+    assert np.array_equal(got, oout)
+    assert np.array_equal(hits.cpu().numpy().astype(np.uint64), ohits)
+
+
+def test_out_of_range_keys_never_match(O, eng):
+    """SURVEY 8c hazard 5: keys 515, 1027, 65539, -1 on a 9-bit column -> no hits, zero bitmap."""
+    import torch
+
+    vals = (np.arange(4096, dtype=np.uint32) * 7) % 512
+    col = eng.compress(torch.from_numpy(vals.view(np.int32)).cuda(), 9)
+    for key in (515, 1027, 65539, -1):
+        bm, hits = eng.scan(key, col)
+        assert int(hits.item()) == 0 and not bm.any().item()
+    bm, hits = eng.scan(511, col)
+    assert int(hits.item()) == int((vals == 511).sum())
+    out, hits = eng.shared_scan([515, 511, -1], col)
+    assert hits.cpu().tolist() == [0, int((vals == 511).sum()), 0]
+
+
+def test_generators_match_oracle(O, eng):
+    for kind, c, param in (("mod", 9, 5), ("mod", 9, 8), ("splitmix", 9, 42), ("splitmix", 21, 42), ("index", 9, 0),
+                           ("splitmix", 12, 7)):
+        n = 50021
+        col = eng.generate(kind, n, c, param, first_row=123456789)
+        vals = O.gen_values(kind, n, c, param, first=123456789)
+        assert np.array_equal(col.data.cpu().numpy(), O.pack(vals, c)), (kind, c)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE sizes: size-independent properties + oracle on sampled windows
+# ------------------------------------------------------------------------------------------------
+
+def test_cfg1_1e7_matches_oracle_exactly(O, eng):
+    """BASELINE config 1: n=1e7, c=9, v=i%5, key 3 (src/benchmark.cpp:173,:150) -> hits 2,000,000."""
+    n, c = 10_000_000, 9
+    col = eng.generate("mod", n, c, 5)
+    bm, hits = eng.scan(3, col)
+    assert int(hits.item()) == 2_000_000
+    packed_host = col.data.cpu().numpy()
+    obm, ohits = O.scan_eq(packed_host, n, c, 3)
+    assert ohits == 2_000_000 and np.array_equal(bm.cpu().numpy(), obm)
+    dec = eng.decompress(col)
+    assert np.array_equal(dec.cpu().numpy(), O.decompress(packed_host, n, c))
+
+
+def test_cfg2_1e9_properties(O, eng):
+    """BASELINE config 2: n=1e9 x 9 bit, equality.  Checks: hit count (i%5 -> exactly n/5), bitmap
+    periodicity (period lcm(5,8)=40 bits = 5 bytes), popcount(bitmap) == hits, and oracle equality on
+    windows sampled at tile-aligned offsets (start, middle, ragged end)."""
+    import torch
+
+    n, c = 1_000_000_000, 9
+    col = eng.generate("mod", n, c, 5)
+    bm, hits = eng.scan(3, col)
+    assert int(hits.item()) == 200_000_000
+    nb = n // 8
+    pat = torch.tensor(np.packbits((np.arange(40) % 5 == 3).astype(np.uint8), bitorder="little"), device="cuda")
+    assert torch.equal(bm[:nb].view(-1, 5), pat.expand(nb // 5, 5))
+    # oracle on windows: rows [a, a+len) with a a multiple of 8192 (byte-aligned in both streams)
+    for a, ln in ((0, 300_000), (8192 * 61_000, 250_000), (n - 123_456 - (n - 123_456) % 8192, None)):
+        ln = n - a if ln is None else ln
+        pk = col.data[a * c // 8: a * c // 8 + (ln * c + 7) // 8].cpu().numpy()
+        obm, _ = O.scan_eq(pk, ln, c, 3)
+        assert np.array_equal(bm[a // 8: a // 8 + (ln + 7) // 8].cpu().numpy(), obm)
+    # random column, key = v[12345]: popcount of the bitmap == hits, windows == oracle
+    col = eng.generate("splitmix", n, c, 42)
+    key = int(O.gen_values("splitmix", 1, c, 42, first=12345)[0])
+    bm, hits = eng.scan(key, col)
+    h = int(hits.item())
+    assert abs(h - n / 512) < 6 * (n / 512) ** 0.5
+    lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device="cuda")
+    assert int(lut[bm.long()].sum().item()) == h
+    for a, ln in ((0, 200_000), (8192 * 100_003, 200_000)):
+        pk = col.data[a * c // 8: a * c // 8 + (ln * c + 7) // 8].cpu().numpy()
+        assert np.array_equal(pk, O.pack(O.gen_values("splitmix", ln, c, 42, first=a), c)[: pk.shape[0]])
+        obm, _ = O.scan_eq(pk, ln, c, key)
+        assert np.array_equal(bm[a // 8: a // 8 + (ln + 7) // 8].cpu().numpy(), obm)
+
+
+@pytest.mark.parametrize("c", [5, 7, 9, 12, 17, 21])
+def test_cfg3_width_sweep_range_properties(O, eng, c):
+    """BASELINE config 3: bit-width sweep, inclusive range [2^c/4, 2^c/2] on the random column (1e8 rows here;
+    bench.py runs 1e9).  decompress -> compare on device gives an independent full-size check."""
+    import torch
+
+    n = 100_000_000
+    col = eng.generate("splitmix", n, c, 42)
+    lo, hi = (1 << c) // 4, (1 << c) // 2
+    bm, hits = eng.scan_range(lo, hi, col)
+    dec = eng.decompress(col)
+    expect = ((dec >= lo) & (dec <= hi))
+    assert int(hits.item()) == int(expect.sum().item())
+    # pack the boolean vector little-endian on the device and compare all n/8 bytes
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device="cuda")
+    packed_expect = (expect.view(-1, 8).to(torch.int32) * w).sum(dim=1).to(torch.uint8)
+    assert torch.equal(bm, packed_expect)
+    a, ln = 8192 * 5000, 150_000
+    pk = col.data[a * c // 8: a * c // 8 + (ln * c + 7) // 8].cpu().numpy()
+    obm, _ = O.scan_range(pk, ln, c, lo, hi)
+    assert np.array_equal(bm[a // 8: a // 8 + (ln + 7) // 8].cpu().numpy(), obm)
+    assert np.array_equal(dec[a: a + ln].cpu().numpy(), O.decompress(pk, ln, c))
+
+
+def test_cfg4_shared_8_predicates_1e9_properties(O, eng):
+    """BASELINE config 4: P=8 over 1e9 x 9 bit, v=i%8, keys 0..7 (src/benchmark.cpp:277,:205-209).
+    Properties: each row matches exactly one key -> the 8 bitmaps partition the rows (OR = all ones,
+    pairwise AND = 0), every hit count = n/8, bitmap k = 0x01<<k repeated; oracle on a window."""
+    import torch
+
+    n, c, P = 1_000_000_000, 9, 8
+    col = eng.generate("mod", n, c, 8)
+    out, hits = eng.shared_scan(list(range(P)), col)
+    assert hits.cpu().tolist() == [n // 8] * P
+    nb = n // 8
+    for k in range(P):
+        assert bool((out[k, :nb] == (1 << k)).all().item())
+    lin, hits2 = eng.shared_scan(list(range(P)), col, layout="linear")
+    assert hits2.cpu().tolist() == [n // 8] * P
+    expect = torch.tensor([1 << k for k in range(P)], dtype=torch.uint8, device="cuda")
+    assert torch.equal(lin.view(-1, P), expect.expand(nb, P))
+    a, ln = 8192 * 77, 100_000
+    pk = col.data[a * c // 8: a * c // 8 + (ln * c + 7) // 8].cpu().numpy()
+    oout, _ = O.shared_scan_eq(pk, ln, c, list(range(P)))
+    assert np.array_equal(out[:, a // 8: a // 8 + (ln + 7) // 8].cpu().numpy(), oout)
