@@ -25,8 +25,9 @@ struct mi355_ctx {
     hipStream_t stream = nullptr;
     int num_cus = 256;
     int max_blocks_per_cu = 0;
-    int dma_aux = 0;
-    unsigned long long *hits_scratch = nullptr; // 1024 counters
+    int dma_aux = 2; // non-temporal HBM->LDS loads: the column is streamed once
+    unsigned long long *hits_scratch = nullptr; // host-pointer API: where the kernels deliver hit counts
+    unsigned long long *kernel_scratch = nullptr; // kScratchDone+1 words, all zero between launches (kernels.hpp hits_finalize)
     int32_t *keys_scratch = nullptr;            // 1024 + 8 keys
 };
 
@@ -51,7 +52,6 @@ int fail(int code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail(MI355_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));        \
     } while (0)
 
-constexpr unsigned kMaxKeys = 1024; // what the reference's linear_simple tops out at (src/simd_scan_shared_linear.cpp:78)
 
 std::mutex g_default_mu;
 mi355_ctx *g_default = nullptr;
@@ -84,6 +84,7 @@ int launch(mi355_ctx *ctx, LaunchReq &r)
     r.num_cus = ctx->num_cus;
     r.max_blocks_per_cu = ctx->max_blocks_per_cu;
     r.dma_aux = ctx->dma_aux;
+    r.scan.scratch = ctx->kernel_scratch;
     hipError_t e = kGroups[(r.c - 1) / 4](r);
     if (e != hipSuccess) return fail(MI355_E_HIP, "kernel launch (op %d, c=%u): %s", r.op, r.c, hipGetErrorString(e));
     return MI355_OK;
@@ -139,6 +140,8 @@ int mi355_ctx_create(int device, void *hip_stream, mi355_ctx **out)
     if (const char *s = getenv("MI355_MAX_BLOCKS_PER_CU")) c->max_blocks_per_cu = atoi(s);
     if (const char *s = getenv("MI355_DMA_AUX")) c->dma_aux = atoi(s);
     hipError_t e = hipMalloc((void **)&c->hits_scratch, kMaxKeys * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->kernel_scratch, (kScratchDone + 8) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(c->kernel_scratch, 0, (kScratchDone + 8) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&c->keys_scratch, (kMaxKeys + 8) * sizeof(int32_t));
     if (e != hipSuccess) {
         delete c;
@@ -154,6 +157,7 @@ int mi355_ctx_destroy(mi355_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->hits_scratch);
+    (void)hipFree(ctx->kernel_scratch);
     (void)hipFree(ctx->keys_scratch);
     {
         std::lock_guard<std::mutex> lk(g_default_mu);
@@ -344,8 +348,10 @@ static int scan_common_dev(mi355_ctx *ctx, int op, const void *packed_dev, uint6
 {
     int rc = check_width(c);
     if (rc) return rc;
-    if (hits_dev) HIP_TRY(hipMemsetAsync(hits_dev, 0, sizeof(uint64_t), ctx->stream));
-    if (n == 0) return MI355_OK;
+    if (n == 0) {
+        if (hits_dev) HIP_TRY(hipMemsetAsync(hits_dev, 0, sizeof(uint64_t), ctx->stream));
+        return MI355_OK;
+    }
     if (!packed_dev || !bitmap_dev) return fail(MI355_E_INVALID, "null device pointer");
     if (((uintptr_t)packed_dev & 15) != 0) return fail(MI355_E_INVALID, "packed_dev must be 16-byte aligned");
     if (((uintptr_t)bitmap_dev & 15) != 0) return fail(MI355_E_INVALID, "bitmap_dev must be 16-byte aligned");
@@ -392,12 +398,14 @@ int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n,
     int rc = resolve(ctx);
     if (rc) return rc;
     if ((rc = check_width(c))) return rc;
-    if (P < 1 || P > kMaxKeys) return fail(MI355_E_INVALID, "P=%u outside 1..%u", P, kMaxKeys);
+    if (P < 1 || P > (unsigned)kMaxKeys) return fail(MI355_E_INVALID, "P=%u outside 1..%u", P, kMaxKeys);
     if (!keys_host) return fail(MI355_E_INVALID, "keys is null");
     if (layout != MI355_LAYOUT_PER_PREDICATE && layout != MI355_LAYOUT_LINEAR)
         return fail(MI355_E_INVALID, "unknown layout %d", layout);
-    if (hits_dev) HIP_TRY(hipMemsetAsync(hits_dev, 0, P * sizeof(uint64_t), ctx->stream));
-    if (n == 0) return MI355_OK;
+    if (n == 0) {
+        if (hits_dev) HIP_TRY(hipMemsetAsync(hits_dev, 0, P * sizeof(uint64_t), ctx->stream));
+        return MI355_OK;
+    }
     if (!packed_dev || !out_dev) return fail(MI355_E_INVALID, "null device pointer");
     if (((uintptr_t)packed_dev & 15) != 0) return fail(MI355_E_INVALID, "packed_dev must be 16-byte aligned");
     if (layout == MI355_LAYOUT_PER_PREDICATE) {
@@ -494,7 +502,7 @@ static int shared_host(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsi
     int rc = resolve(ctx);
     if (rc) return rc;
     if ((rc = check_width(c))) return rc;
-    if (P < 1 || P > kMaxKeys) return fail(MI355_E_INVALID, "P=%u outside 1..%u", P, kMaxKeys);
+    if (P < 1 || P > (unsigned)kMaxKeys) return fail(MI355_E_INVALID, "P=%u outside 1..%u", P, kMaxKeys);
     if (!keys) return fail(MI355_E_INVALID, "keys is null");
     if (hits) memset(hits, 0, P * sizeof(uint64_t));
     if (n == 0) return MI355_OK;
@@ -559,7 +567,7 @@ const char *mi355_kernel_name(const char *op, unsigned c)
 uint64_t mi355_tile_values(unsigned c)
 {
     if (c < 1 || c > 32) return 0;
-    return c <= 16 ? 8192 : 4096;
+    return 64 * (uint64_t)scan_vpl((int)c, kModeEq);
 }
 
 } // extern "C"

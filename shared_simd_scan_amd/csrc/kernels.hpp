@@ -30,34 +30,53 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = kWavesPerBlock * 64;
 constexpr int kMaxKeysPerPass = 8;
+constexpr int kMaxKeys = 1024;      // what the reference's linear_simple tops out at (src/simd_scan_shared_linear.cpp:78)
+constexpr int kScratchDone = kMaxKeys; // index of the "waves finished" counter in the scratch array
 
 // ---- tile geometry of the scan kernels -----------------------------------------------------
 // A wave owns a tile of 64*VPL consecutive values; lane l owns values [l*VPL, (l+1)*VPL) of it,
-// i.e. VPL*C bits = LANE_DWORDS whole dwords starting on a dword boundary.
-template <int C> struct ScanGeom {
-    static constexpr int VPL = (C <= 16) ? 128 : 64;      // values per lane per tile
+// i.e. VPL*C bits = LANE_DWORDS whole dwords starting on a dword boundary.  VPL in {32, 64, 128}
+// selects the LDS read width (ds_read_b32 / b64 / b128) and the bitmap store width (4 / 8 / 16 B).
+template <int C, int VPL> struct ScanGeom {
+    static_assert(VPL == 32 || VPL == 64 || VPL == 128, "VPL");
     static constexpr int WORDS = VPL / 32;                 // bitmap dwords per lane per tile
-    static constexpr int LANE_DWORDS = VPL * C / 32;       // packed dwords per lane (4C or 2C)
-    static constexpr int LANE_BYTES = LANE_DWORDS * 4;     // 16C or 8C
-    static constexpr int TILE_VALUES = 64 * VPL;           // 8192 or 4096
-    static constexpr int TILE_BYTES = 64 * LANE_BYTES;     // 1024C or 512C
+    static constexpr int LANE_DWORDS = VPL * C / 32;       // packed dwords per lane
+    static constexpr int LANE_BYTES = LANE_DWORDS * 4;
+    static constexpr int TILE_VALUES = 64 * VPL;
+    static constexpr int TILE_BYTES = 64 * LANE_BYTES;
     static constexpr int DMA_INSTRS = (TILE_BYTES + 1023) / 1024;
     static constexpr int LDS_BYTES = DMA_INSTRS * 1024;    // per wave
-    static constexpr int BITMAP_BYTES = TILE_VALUES / 8;   // 1024 or 512 per tile
-    // waves per SIMD the LDS footprint admits (160 KiB per CU, 4 waves per block), capped at 4:
-    // the register allocator is told to aim for exactly that
+    static constexpr int BITMAP_BYTES = TILE_VALUES / 8;
+    // waves per SIMD the LDS footprint admits (160 KiB per CU, 4 waves per block), capped at 8:
+    // the register allocator is told to aim for that
     static constexpr int OCC_LDS = (160 * 1024) / (4 * LDS_BYTES);
-    static constexpr int OCC = OCC_LDS >= 4 ? 4 : (OCC_LDS < 1 ? 1 : OCC_LDS);
+    static constexpr int OCC = OCC_LDS >= 8 ? 8 : (OCC_LDS < 1 ? 1 : OCC_LDS);
 };
 
 enum ScanMode { kModeEq = 0, kModeRange = 1, kModeShared = 2 };
+
+// occupancy target handed to the register allocator: what LDS admits, but the 8-key shared scan keeps
+// 8 accumulators + 8x(VPL/32) result words + hit counters live and wants up to 128 VGPRs
+template <int C, int VPL, int MODE> constexpr int scan_occ()
+{
+    constexpr int lds = ScanGeom<C, VPL>::OCC;
+    return MODE == 2 ? (lds > 4 ? 4 : lds) : lds;
+}
+
+// values per lane per tile used by the shipped dispatch (tools/tune_scan.hip sweeps the alternatives)
+constexpr int scan_vpl(int C, int MODE)
+{
+    if (MODE == kModeShared) return 64;
+    return C <= 16 ? 128 : 64;
+}
 
 struct ScanArgs {
     const uint8_t *packed;     // 16 B aligned
     uint64_t n;                // values
     uint8_t *out;              // bitmap(s)
     uint64_t out_stride;       // bytes between per-predicate bitmaps (kModeShared, layout 0)
-    unsigned long long *hits;  // device counters (one per key), pre-zeroed, may be null
+    unsigned long long *hits;  // device counters (one per key), OVERWRITTEN with the totals; may be null
+    unsigned long long *scratch; // context scratch: kScratchDone+1 words, all zero between launches
     const int32_t *keys_dev;   // kModeShared with P > kMaxKeysPerPass: device key array (padded to 8)
     uint32_t key[kMaxKeysPerPass]; // kModeEq: key[0]; kModeRange: key[0]=lo, key[1]=hi-lo; kModeShared: P<=8 keys
     uint32_t nkeys;            // P
@@ -67,16 +86,16 @@ struct ScanArgs {
 // ---- DMA: HBM -> LDS ---------------------------------------------------------------------------
 // One wave-instruction moves 64 x 16 B; the LDS destination is wave-uniform base + lane*16, the
 // global source is per lane.  AUX carries the cache-policy bits (0 default, 2 = nt).
-template <int C, int AUX>
+template <int TILE_BYTES, int AUX>
 __device__ __forceinline__ void dma_tile_full(const uint8_t *src, uint8_t *lds_wave, int lane)
 {
-    using G = ScanGeom<C>;
+    constexpr int N = (TILE_BYTES + 1023) / 1024;
 #pragma unroll
-    for (int j = 0; j < G::DMA_INSTRS; j++) {
-        if ((j + 1) * 1024 <= G::TILE_BYTES) {
+    for (int j = 0; j < N; j++) {
+        if ((j + 1) * 1024 <= TILE_BYTES) {
             __builtin_amdgcn_global_load_lds(MI355_GPTR(src + j * 1024 + lane * 16), MI355_LPTR(lds_wave + j * 1024), 16,
                                              0, AUX);
-        } else if (lane * 16 < G::TILE_BYTES - j * 1024) { // trailing half instruction (odd C at VPL 64)
+        } else if (lane * 16 < TILE_BYTES - j * 1024) { // trailing partial instruction
             __builtin_amdgcn_global_load_lds(MI355_GPTR(src + j * 1024 + lane * 16), MI355_LPTR(lds_wave + j * 1024), 16,
                                              0, AUX);
         }
@@ -86,14 +105,14 @@ __device__ __forceinline__ void dma_tile_full(const uint8_t *src, uint8_t *lds_w
 // Last (partial) tile: only 16-byte chunks that start inside the payload are fetched.  A chunk may
 // run up to 15 bytes past the payload: that is inside the 256-byte pad every packed buffer carries
 // (src/simd_scan.hpp:20-26).  Whatever stays stale in LDS only feeds bits >= n, which are masked.
-template <int C, int AUX>
+template <int TILE_BYTES, int AUX>
 __device__ __forceinline__ void dma_tile_partial(const uint8_t *src, uint64_t bytes_left, uint8_t *lds_wave, int lane)
 {
-    using G = ScanGeom<C>;
+    constexpr int N = (TILE_BYTES + 1023) / 1024;
 #pragma unroll
-    for (int j = 0; j < G::DMA_INSTRS; j++) {
+    for (int j = 0; j < N; j++) {
         uint32_t o = j * 1024 + lane * 16;
-        if (o < G::TILE_BYTES && o < bytes_left) {
+        if (o < TILE_BYTES && o < bytes_left) {
             __builtin_amdgcn_global_load_lds(MI355_GPTR(src + o), MI355_LPTR(lds_wave + j * 1024), 16, 0, AUX);
         }
     }
@@ -126,6 +145,31 @@ __device__ __forceinline__ void push_eq(uint32_t &acc, uint32_t x, uint32_t key)
         : "vcc");
 }
 
+// the same for 8 keys against one value, as ONE asm statement (between separate asm statements that
+// clobber VCC hipcc inserts an s_nop per pair)
+__device__ __forceinline__ void push_eq8(uint32_t (&acc)[8], uint32_t x, const uint32_t (&key)[kMaxKeysPerPass])
+{
+    asm("v_cmp_eq_u32_e32 vcc, %9, %8\n\t"
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+        "v_cmp_eq_u32_e32 vcc, %10, %8\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\t"
+        "v_cmp_eq_u32_e32 vcc, %11, %8\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc\n\t"
+        "v_cmp_eq_u32_e32 vcc, %12, %8\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %3, %3, vcc\n\t"
+        "v_cmp_eq_u32_e32 vcc, %13, %8\n\t"
+        "v_addc_co_u32_e32 %4, vcc, %4, %4, vcc\n\t"
+        "v_cmp_eq_u32_e32 vcc, %14, %8\n\t"
+        "v_addc_co_u32_e32 %5, vcc, %5, %5, vcc\n\t"
+        "v_cmp_eq_u32_e32 vcc, %15, %8\n\t"
+        "v_addc_co_u32_e32 %6, vcc, %6, %6, vcc\n\t"
+        "v_cmp_eq_u32_e32 vcc, %16, %8\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %7, %7, vcc"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+        : "v"(x), "s"(key[0]), "s"(key[1]), "s"(key[2]), "s"(key[3]), "s"(key[4]), "s"(key[5]), "s"(key[6]), "s"(key[7])
+        : "vcc");
+}
+
 // acc = 2*acc + (x - lo <= span)   (unsigned: lo <= x <= lo+span)
 __device__ __forceinline__ void push_range(uint32_t &acc, uint32_t x, uint32_t lo, uint32_t span)
 {
@@ -146,6 +190,8 @@ __device__ __forceinline__ void decode_step(const uint32_t (&w)[NW], uint32_t (&
     uint32_t x = extract<C, 32 * J + K, NW>(w);
     if constexpr (MODE == kModeRange) {
         push_range(acc[0], x, key[0], key[1]);
+    } else if constexpr (NK == 8) {
+        push_eq8(acc, x, key);
     } else {
 #pragma unroll
         for (int q = 0; q < NK; q++) push_eq(acc[q], x, key[q]);
@@ -153,24 +199,32 @@ __device__ __forceinline__ void decode_step(const uint32_t (&w)[NW], uint32_t (&
     if constexpr (K > 0) decode_step<C, J, K - 1, NK, MODE, NW>(w, acc, key);
 }
 
+// bitmap word J (values 32J..32J+31 of the lane) for each of NK predicates
 template <int C, int J, int NK, int MODE, int NW>
-__device__ __forceinline__ void decode_words(const uint32_t (&w)[NW], uint32_t (&res)[NK][ScanGeom<C>::WORDS],
-                                             const uint32_t (&key)[kMaxKeysPerPass])
+__device__ __forceinline__ void decode_word(const uint32_t (&w)[NW], uint32_t (&acc)[NK], const uint32_t (&key)[kMaxKeysPerPass])
 {
-    uint32_t acc[NK];
 #pragma unroll
     for (int q = 0; q < NK; q++) acc[q] = 0;
     decode_step<C, J, 31, NK, MODE, NW>(w, acc, key);
-#pragma unroll
-    for (int q = 0; q < NK; q++) res[q][J] = acc[q];
-    if constexpr (J + 1 < ScanGeom<C>::WORDS) decode_words<C, J + 1, NK, MODE, NW>(w, res, key);
 }
 
-// lane-local packed data: LDS -> VGPRs (ds_read_b128 at VPL 128, ds_read_b64 at VPL 64)
-template <int C> __device__ __forceinline__ void read_lane_data(const uint8_t *lds_wave, int lane, uint32_t (&w)[ScanGeom<C>::LANE_DWORDS])
+template <int C, int VPL, int J, int NK, int MODE, int NW>
+__device__ __forceinline__ void decode_words(const uint32_t (&w)[NW], uint32_t (&res)[NK][VPL / 32],
+                                             const uint32_t (&key)[kMaxKeysPerPass])
 {
-    using G = ScanGeom<C>;
-    if constexpr (G::VPL == 128) {
+    uint32_t acc[NK];
+    decode_word<C, J, NK, MODE, NW>(w, acc, key);
+#pragma unroll
+    for (int q = 0; q < NK; q++) res[q][J] = acc[q];
+    if constexpr (J + 1 < VPL / 32) decode_words<C, VPL, J + 1, NK, MODE, NW>(w, res, key);
+}
+
+// lane-local packed data: LDS -> VGPRs (ds_read_b128 / b64 / b32 by VPL)
+template <int C, int VPL>
+__device__ __forceinline__ void read_lane_data(const uint8_t *lds_wave, int lane, uint32_t (&w)[VPL * C / 32])
+{
+    using G = ScanGeom<C, VPL>;
+    if constexpr (VPL == 128) {
         const u32x4 *p = (const u32x4 *)(lds_wave + lane * G::LANE_BYTES);
 #pragma unroll
         for (int q = 0; q < C; q++) {
@@ -180,7 +234,7 @@ template <int C> __device__ __forceinline__ void read_lane_data(const uint8_t *l
             w[4 * q + 2] = v.z;
             w[4 * q + 3] = v.w;
         }
-    } else {
+    } else if constexpr (VPL == 64) {
         const u32x2 *p = (const u32x2 *)(lds_wave + lane * G::LANE_BYTES);
 #pragma unroll
         for (int q = 0; q < C; q++) {
@@ -188,6 +242,10 @@ template <int C> __device__ __forceinline__ void read_lane_data(const uint8_t *l
             w[2 * q + 0] = v.x;
             w[2 * q + 1] = v.y;
         }
+    } else {
+        const uint32_t *p = (const uint32_t *)(lds_wave + lane * G::LANE_BYTES);
+#pragma unroll
+        for (int q = 0; q < C; q++) w[q] = p[q];
     }
 }
 
@@ -205,15 +263,68 @@ __device__ __forceinline__ uint32_t tail_mask(int valid, int J)
     return v >= 32 ? 0xffffffffu : (v <= 0 ? 0u : ((1u << v) - 1u));
 }
 
-// ---- the scan kernel ------------------------------------------------------------------------
-// MODE kModeEq / kModeRange: one bitmap, software-pipelined (the DMA of the wave's next tile is in
-// flight while the current one is decoded).  MODE kModeShared: NK = 8 keys per pass over the lane's
-// registers, P/8 passes per tile, the column is read from HBM once.
-template <int C, int MODE, int AUX>
-__global__ __launch_bounds__(kBlockThreads, ScanGeom<C>::OCC) void scan_kernel(ScanArgs a)
+template <int WORDS> __device__ __forceinline__ void store_words(uint8_t *dst, const uint32_t (&v)[WORDS])
 {
-    using G = ScanGeom<C>;
+    if constexpr (WORDS == 4) {
+        u32x4 t = {v[0], v[1], v[2], v[3]};
+        *(u32x4 *)dst = t;
+    } else if constexpr (WORDS == 2) {
+        u32x2 t = {v[0], v[1]};
+        *(u32x2 *)dst = t;
+    } else {
+        *(uint32_t *)dst = v[0];
+    }
+}
+
+// ---- hit counts without a memset launch ---------------------------------------------------------
+// Every wave adds its per-key counts to the context's scratch totals, waits until those adds have been
+// performed, then takes a ticket on the "done" counter.  All of these are device-scope atomic RMWs, which
+// gfx950 executes at the memory side (coherent across the 8 XCDs, never held in a CU's L1 or an XCD's L2),
+// so no cache write-back / invalidate is needed -- a per-wave agent-scope release fence (buffer_wbl2) here
+// cost 25 % of the kernel when launches run back to back.  The wave that draws the last ticket therefore
+// sees every other wave's adds: it moves the totals to the caller's `hits` array with atomic exchanges that
+// also zero the scratch for the next launch.  One kernel launch per scan.
+__device__ __forceinline__ void hits_add(const ScanArgs &a, uint32_t k, uint32_t wave_total, int lane)
+{
+    if (lane == 0 && wave_total)
+        __hip_atomic_fetch_add(a.scratch + k, (unsigned long long)wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void hits_finalize(const ScanArgs &a, uint32_t P, int lane)
+{
+    if (!a.hits) return;
+    unsigned long long ticket = 0;
+    // this wave's adds are complete (vmcnt counts atomics) before its ticket is drawn
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+        ticket = __hip_atomic_fetch_add(a.scratch + kScratchDone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __shfl(ticket, 0, 64);
+    const unsigned long long nwaves = (unsigned long long)gridDim.x * kWavesPerBlock;
+    if (ticket == nwaves - 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (uint32_t k = lane; k < P; k += 64) {
+            a.hits[k] = __hip_atomic_exchange(a.scratch + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) __hip_atomic_store(a.scratch + kScratchDone, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- the scan kernel ------------------------------------------------------------------------
+// Per wave, per tile:  wait for the tile's DMA -> ds_read the lane's run into VGPRs -> (LDS is free)
+// store the PREVIOUS tile's bitmap words, then issue the NEXT tile's DMA -> decode/compare in registers.
+// Stores are issued before the DMA that the next iteration waits for, so a plain vmcnt(0) never waits
+// on a store younger than the data it needs, whatever the number of stores per tile is; the DMA of
+// tile t+1 is in flight during the whole compute phase of tile t.
+//
+// MODE kModeEq / kModeRange: one bitmap.  MODE kModeShared: 8 keys per pass over the lane's registers
+// (one decode, 8 compares per value), ceil(P/8) passes per tile; the column is read from HBM once.
+// ABL (ablation, tools/tune_scan.hip only): 1 = DMA only, 2 = DMA + LDS reads, 3 = no bitmap stores.
+template <int C, int MODE, int AUX, int VPL, int ABL = 0>
+__global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void scan_kernel(ScanArgs a)
+{
+    using G = ScanGeom<C, VPL>;
     constexpr int NK = (MODE == kModeShared) ? kMaxKeysPerPass : 1;
+    constexpr int WORDS = G::WORDS;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
 
     const int lane = threadIdx.x & 63;
@@ -227,94 +338,127 @@ __global__ __launch_bounds__(kBlockThreads, ScanGeom<C>::OCC) void scan_kernel(S
     const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
     uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
 
-    uint32_t hits[NK];
-#pragma unroll
-    for (int q = 0; q < NK; q++) hits[q] = 0;
-
     auto issue = [&](uint64_t t) {
         const uint8_t *src = a.packed + t * G::TILE_BYTES;
         if (t < nfull)
-            dma_tile_full<C, AUX>(src, lds_wave, lane);
+            dma_tile_full<G::TILE_BYTES, AUX>(src, lds_wave, lane);
         else
-            dma_tile_partial<C, AUX>(src, data_bytes - t * G::TILE_BYTES, lds_wave, lane);
+            dma_tile_partial<G::TILE_BYTES, AUX>(src, data_bytes - t * G::TILE_BYTES, lds_wave, lane);
+    };
+    // tail tile: zero bits >= n, write exactly ceil(n/8) bytes of the tile's bitmap
+    auto finish_tail = [&](uint64_t t, uint32_t (&v)[WORDS], uint8_t *dst, uint64_t byte_stride) -> uint32_t {
+        const int64_t left = (int64_t)(n - t * G::TILE_VALUES) - (int64_t)lane * VPL;
+        const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
+        const int nbytes = (valid + 7) / 8;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < WORDS; j++) {
+            v[j] &= tail_mask(valid, j);
+            cnt += __builtin_popcount(v[j]);
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (4 * j + b < nbytes) dst[(uint64_t)(4 * j + b) * byte_stride] = (uint8_t)(v[j] >> (8 * b));
+        }
+        return cnt;
     };
 
-    if constexpr (MODE != kModeShared) {
-        // ---------------- single-predicate, prefetching loop ----------------
+    const uint32_t P = (MODE == kModeShared) ? a.nkeys : 1;
+    const bool one_pass = P <= (uint32_t)kMaxKeysPerPass;
+
+    if (MODE != kModeShared || (one_pass && a.layout == 0)) {
+        // ---------------- pipelined loop: one pass of NK keys, per-predicate bitmaps ----------------
         uint32_t key[kMaxKeysPerPass];
 #pragma unroll
         for (int q = 0; q < kMaxKeysPerPass; q++) key[q] = a.key[q];
+        uint32_t hits[NK];
+#pragma unroll
+        for (int q = 0; q < NK; q++) hits[q] = 0;
 
+        uint32_t res[NK][WORDS];
+        uint64_t prev = ~0ull; // tile whose results sit in `res`, not yet stored
         if (tile < ntiles) issue(tile);
-        bool first = true;
         while (tile < ntiles) {
-            // the tile's DMA is older than the single store of the previous iteration
-            if (first)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            first = false;
-
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             uint32_t w[G::LANE_DWORDS];
-            read_lane_data<C>(lds_wave, lane, w);
+            if constexpr (ABL != 1) read_lane_data<C, VPL>(lds_wave, lane, w);
             // the LDS tile must be fully read before the next DMA may overwrite it
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (prev != ~0ull) { // every tile but a wave's last is a full tile
+                if constexpr (ABL == 0) {
+#pragma unroll
+                    for (int q = 0; q < NK; q++)
+                        if ((uint32_t)q < P)
+                            store_words<WORDS>(a.out + (uint64_t)q * a.out_stride + prev * G::BITMAP_BYTES + lane * (WORDS * 4), res[q]);
+                }
+            }
             const uint64_t next = tile + stride;
             if (next < ntiles) issue(next);
 
-            uint32_t res[1][G::WORDS];
-            decode_words<C, 0, 1, MODE, G::LANE_DWORDS>(w, res, key);
-
-            uint8_t *dst = a.out + tile * G::BITMAP_BYTES + lane * (G::WORDS * 4);
+            if constexpr (ABL == 1) {
+#pragma unroll
+                for (int q = 0; q < NK; q++)
+#pragma unroll
+                    for (int j = 0; j < WORDS; j++) res[q][j] = 0;
+            } else if constexpr (ABL == 2) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int i = 0; i < G::LANE_DWORDS; i++) x ^= w[i];
+#pragma unroll
+                for (int q = 0; q < NK; q++)
+#pragma unroll
+                    for (int j = 0; j < WORDS; j++) res[q][j] = x;
+            } else {
+                decode_words<C, VPL, 0, NK, MODE, G::LANE_DWORDS>(w, res, key);
+            }
             if (tile < nfull) {
 #pragma unroll
-                for (int j = 0; j < G::WORDS; j++) hits[0] += __builtin_popcount(res[0][j]);
-                if constexpr (G::WORDS == 4) {
-                    u32x4 v = {res[0][0], res[0][1], res[0][2], res[0][3]};
-                    *(u32x4 *)dst = v;
-                } else {
-                    u32x2 v = {res[0][0], res[0][1]};
-                    *(u32x2 *)dst = v;
-                }
+                for (int q = 0; q < NK; q++)
+#pragma unroll
+                    for (int j = 0; j < WORDS; j++) hits[q] += __builtin_popcount(res[q][j]);
+                prev = tile;
             } else {
-                // tail tile: zero bits >= n, write exactly ceil(n/8) bytes
-                const int64_t left = (int64_t)(n - tile * G::TILE_VALUES) - (int64_t)lane * G::VPL;
-                const int valid = left >= G::VPL ? G::VPL : (left <= 0 ? 0 : (int)left);
-                const int nbytes = (valid + 7) / 8;
 #pragma unroll
-                for (int j = 0; j < G::WORDS; j++) {
-                    uint32_t v = res[0][j] & tail_mask(valid, j);
-                    hits[0] += __builtin_popcount(v);
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (4 * j + b < nbytes) dst[4 * j + b] = (uint8_t)(v >> (8 * b));
-                }
+                for (int q = 0; q < NK; q++)
+                    if ((uint32_t)q < P)
+                        hits[q] += finish_tail(tile, res[q], a.out + (uint64_t)q * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4), 1);
+                prev = ~0ull;
             }
             tile = next;
         }
-        if (a.hits) {
-            uint32_t s = wave_sum(hits[0]);
-            if (lane == 0 && s) atomicAdd(a.hits, (unsigned long long)s);
+        if (prev != ~0ull) {
+            if constexpr (ABL == 0) {
+#pragma unroll
+                for (int q = 0; q < NK; q++)
+                    if ((uint32_t)q < P)
+                        store_words<WORDS>(a.out + (uint64_t)q * a.out_stride + prev * G::BITMAP_BYTES + lane * (WORDS * 4), res[q]);
+            } else if (res[0][0] == 0x12345678u) { // keep the ablated pipeline alive
+                a.out[lane] = 1;
+            }
         }
-    } else {
-        // ---------------- shared scan: decode once, P compares ----------------
-        const uint32_t P = a.nkeys;
+        if (a.hits) {
+#pragma unroll
+            for (int q = 0; q < NK; q++) {
+                uint32_t s = wave_sum(hits[q]);
+                if ((uint32_t)q < P) hits_add(a, q, s, lane);
+            }
+        }
+        hits_finalize(a, P, lane);
+    } else if constexpr (MODE == kModeShared) {
+        // ---------------- general shared scan: any P (multi-pass), either layout ----------------
         const uint32_t npass = (P + kMaxKeysPerPass - 1) / kMaxKeysPerPass;
+        if (tile < ntiles) issue(tile);
         while (tile < ntiles) {
-            issue(tile);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             uint32_t w[G::LANE_DWORDS];
-            read_lane_data<C>(lds_wave, lane, w);
+            read_lane_data<C, VPL>(lds_wave, lane, w);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
+            const uint64_t next = tile + stride;
+            if (next < ntiles) issue(next);
             const bool full = tile < nfull;
-            const int64_t left = (int64_t)(n - tile * G::TILE_VALUES) - (int64_t)lane * G::VPL;
-            const int valid = left >= G::VPL ? G::VPL : (left <= 0 ? 0 : (int)left);
-            const int nbytes = (valid + 7) / 8;
 
             for (uint32_t pass = 0; pass < npass; pass++) {
                 uint32_t key[kMaxKeysPerPass];
-                if (npass == 1) {
+                if (one_pass) {
 #pragma unroll
                     for (int q = 0; q < kMaxKeysPerPass; q++) key[q] = a.key[q];
                 } else {
@@ -322,60 +466,43 @@ __global__ __launch_bounds__(kBlockThreads, ScanGeom<C>::OCC) void scan_kernel(S
                     for (int q = 0; q < kMaxKeysPerPass; q++)
                         key[q] = __builtin_amdgcn_readfirstlane((uint32_t)a.keys_dev[pass * kMaxKeysPerPass + q]);
                 }
-                uint32_t res[NK][G::WORDS];
-                decode_words<C, 0, NK, MODE, G::LANE_DWORDS>(w, res, key);
+                uint32_t res[NK][WORDS];
+                decode_words<C, VPL, 0, NK, MODE, G::LANE_DWORDS>(w, res, key);
 #pragma unroll
                 for (int q = 0; q < NK; q++) {
                     const uint32_t k = pass * kMaxKeysPerPass + q;
-                    if (k >= P) break;
-                    uint32_t v[G::WORDS];
+                    if (k < P) {
                     uint32_t cnt = 0;
-#pragma unroll
-                    for (int j = 0; j < G::WORDS; j++) {
-                        v[j] = full ? res[q][j] : (res[q][j] & tail_mask(valid, j));
-                        cnt += __builtin_popcount(v[j]);
-                    }
-                    if (npass == 1) {
-                        hits[q] += cnt;
-                    } else if (a.hits) {
-                        uint32_t s = wave_sum(cnt);
-                        if (lane == 0 && s) atomicAdd(a.hits + k, (unsigned long long)s);
-                    }
                     if (a.layout == 0) {
-                        uint8_t *dst = a.out + (uint64_t)k * a.out_stride + tile * G::BITMAP_BYTES + lane * (G::WORDS * 4);
+                        uint8_t *dst = a.out + (uint64_t)k * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4);
                         if (full) {
-                            if constexpr (G::WORDS == 4) {
-                                u32x4 t = {v[0], v[1], v[2], v[3]};
-                                *(u32x4 *)dst = t;
-                            } else {
-                                u32x2 t = {v[0], v[1]};
-                                *(u32x2 *)dst = t;
-                            }
-                        } else {
 #pragma unroll
-                            for (int b = 0; b < G::WORDS * 4; b++)
-                                if (b < nbytes) dst[b] = (uint8_t)(v[b >> 2] >> (8 * (b & 3)));
+                            for (int j = 0; j < WORDS; j++) cnt += __builtin_popcount(res[q][j]);
+                            store_words<WORDS>(dst, res[q]);
+                        } else {
+                            cnt = finish_tail(tile, res[q], dst, 1);
                         }
                     } else {
-                        // linear: byte of 8-value group g and key k at g*P + k
-                        // (src/simd_scan_shared_linear.cpp:57)
-                        const uint64_t g0 = tile * G::BITMAP_BYTES + (uint64_t)lane * (G::WORDS * 4);
+                        // linear: byte of 8-value group g and key k at g*P + k (src/simd_scan_shared_linear.cpp:57)
+                        uint8_t *dst = a.out + (tile * G::BITMAP_BYTES + (uint64_t)lane * (WORDS * 4)) * P + k;
+                        if (full) {
 #pragma unroll
-                        for (int b = 0; b < G::WORDS * 4; b++)
-                            if (b < nbytes) a.out[(g0 + b) * P + k] = (uint8_t)(v[b >> 2] >> (8 * (b & 3)));
+                            for (int j = 0; j < WORDS; j++) {
+                                cnt += __builtin_popcount(res[q][j]);
+#pragma unroll
+                                for (int b = 0; b < 4; b++) dst[(uint64_t)(4 * j + b) * P] = (uint8_t)(res[q][j] >> (8 * b));
+                            }
+                        } else {
+                            cnt = finish_tail(tile, res[q], dst, P);
+                        }
+                    }
+                    if (a.hits) hits_add(a, k, wave_sum(cnt), lane);
                     }
                 }
             }
-            tile += stride;
+            tile = next;
         }
-        if (a.hits && npass == 1) {
-#pragma unroll
-            for (int q = 0; q < NK; q++) {
-                if ((uint32_t)q >= P) break;
-                uint32_t s = wave_sum(hits[q]);
-                if (lane == 0 && s) atomicAdd(a.hits + q, (unsigned long long)s);
-            }
-        }
+        hits_finalize(a, P, lane);
     }
 }
 

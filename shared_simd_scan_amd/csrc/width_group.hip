@@ -23,38 +23,46 @@ inline int cap_bpc(int bpc, const LaunchReq &r)
     return (r.max_blocks_per_cu > 0 && r.max_blocks_per_cu < bpc) ? r.max_blocks_per_cu : bpc;
 }
 
+// Resident blocks per CU for the streaming scans.  Measured on MI355X (tools/sweep.py, 1e9 rows): the scans
+// run fastest with ~36-48 KiB of LDS-DMA in flight per CU -- one 4-wave block at c=9 (4 x 9 KiB tiles) --
+// and lose 3-6 % at the occupancy limit (more concurrent streams, same bytes).  So: the number of blocks
+// whose tiles add up to ~40 KiB, at least 1, at most what the occupancy query admits.
+inline int scan_bpc(int occ_bpc, int tile_bytes, const LaunchReq &r)
+{
+    if (r.max_blocks_per_cu > 0) return r.max_blocks_per_cu < occ_bpc ? r.max_blocks_per_cu : occ_bpc;
+    int want = (40 * 1024 + 2 * tile_bytes) / (kWavesPerBlock * tile_bytes); // rounded
+    if (want < 1) want = 1;
+    return want < occ_bpc ? want : occ_bpc;
+}
+
+template <int C, int MODE> void launch_scan(const LaunchReq &r)
+{
+    constexpr int VPL = scan_vpl(C, MODE);
+    using G = ScanGeom<C, VPL>;
+    static const int bpc = blocks_per_cu(scan_kernel<C, MODE, 2, VPL>);
+    const uint64_t ntiles = (r.scan.n + G::TILE_VALUES - 1) / G::TILE_VALUES;
+    const unsigned grid = grid_for(ntiles, scan_bpc(bpc, G::TILE_BYTES, r), r.num_cus);
+    // dma_aux: cache policy of the HBM->LDS stream; 2 (non-temporal: the column is read once) is the default
+    if (r.dma_aux == 0)
+        hipLaunchKernelGGL((scan_kernel<C, MODE, 0, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
+    else
+        hipLaunchKernelGGL((scan_kernel<C, MODE, 2, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
+}
+
 template <int C> hipError_t launch_width(const LaunchReq &r)
 {
     switch (r.op) {
-    case kOpScanEq: {
-        static const int bpc = blocks_per_cu(scan_kernel<C, kModeEq, 0>);
-        const uint64_t ntiles = (r.scan.n + ScanGeom<C>::TILE_VALUES - 1) / ScanGeom<C>::TILE_VALUES;
-        const unsigned grid = grid_for(ntiles, cap_bpc(bpc, r), r.num_cus);
-        if (r.dma_aux == 2)
-            hipLaunchKernelGGL((scan_kernel<C, kModeEq, 2>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
-        else
-            hipLaunchKernelGGL((scan_kernel<C, kModeEq, 0>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
-        break;
-    }
-    case kOpScanRange: {
-        static const int bpc = blocks_per_cu(scan_kernel<C, kModeRange, 0>);
-        const uint64_t ntiles = (r.scan.n + ScanGeom<C>::TILE_VALUES - 1) / ScanGeom<C>::TILE_VALUES;
-        const unsigned grid = grid_for(ntiles, cap_bpc(bpc, r), r.num_cus);
-        hipLaunchKernelGGL((scan_kernel<C, kModeRange, 0>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
-        break;
-    }
-    case kOpSharedScan: {
-        static const int bpc = blocks_per_cu(scan_kernel<C, kModeShared, 0>);
-        const uint64_t ntiles = (r.scan.n + ScanGeom<C>::TILE_VALUES - 1) / ScanGeom<C>::TILE_VALUES;
-        const unsigned grid = grid_for(ntiles, cap_bpc(bpc, r), r.num_cus);
-        hipLaunchKernelGGL((scan_kernel<C, kModeShared, 0>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
-        break;
-    }
+    case kOpScanEq: launch_scan<C, kModeEq>(r); break;
+    case kOpScanRange: launch_scan<C, kModeRange>(r); break;
+    case kOpSharedScan: launch_scan<C, kModeShared>(r); break;
     case kOpDecompress: {
-        static const int bpc = blocks_per_cu(decompress_kernel<C, 0>);
+        static const int bpc = blocks_per_cu(decompress_kernel<C, 2>);
         const uint64_t ntiles = (r.decomp.n + DecompGeom<C>::TILE_VALUES - 1) / DecompGeom<C>::TILE_VALUES;
         const unsigned grid = grid_for(ntiles, cap_bpc(bpc, r), r.num_cus);
-        hipLaunchKernelGGL((decompress_kernel<C, 0>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);
+        if (r.dma_aux == 0)
+            hipLaunchKernelGGL((decompress_kernel<C, 0>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);
+        else
+            hipLaunchKernelGGL((decompress_kernel<C, 2>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);
         break;
     }
     default:

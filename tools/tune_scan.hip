@@ -1,0 +1,200 @@
+// tune_scan.hip -- standalone tuning / ablation harness for the scan kernels (not part of the product).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/tune_scan.hip -o tools/tune_scan
+// Run on the GPU box: tools/tune_scan [rows] [bits=9 only] [column: 0 mod5 | 1 random]
+// Every variant is timed with hipEvents per launch (median / min of REPS), interleaved in rounds as
+// the CDNA guide asks (rule 24), and checked against the hit count of the first variant.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../shared_simd_scan_amd/csrc/kernels.hpp"
+
+using namespace mi355;
+
+#define CK(x)                                                                                     \
+    do {                                                                                          \
+        hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) {                                                                   \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));     \
+            exit(1);                                                                              \
+        }                                                                                         \
+    } while (0)
+
+// plain streaming-read reference: 16 B / lane loads, XOR-reduced, nothing written (read ceiling)
+template <int UNROLL, int NT> __global__ __launch_bounds__(256) void read_kernel(const u32x4 *p, uint64_t nvec, uint32_t *sink)
+{
+    u32x4 acc = {0, 0, 0, 0};
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            if (NT)
+                v[u] = __builtin_nontemporal_load(p + i + u * stride);
+            else
+                v[u] = p[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) acc ^= v[u];
+    }
+    for (; i < nvec; i += stride) acc ^= p[i];
+    uint32_t x = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (x == 0x12345678u) *sink = x;
+}
+
+struct Variant {
+    std::string name;
+    std::function<void(int bpc, hipStream_t)> launch;
+    int max_bpc;
+    double bytes; // algorithmic bytes per launch
+    bool counts_hits;
+};
+
+int main(int argc, char **argv)
+{
+    const uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1000000000ull;
+    const int column = argc > 3 ? atoi(argv[3]) : 0;
+    const int REPS = argc > 4 ? atoi(argv[4]) : 15;
+    const int NOHITS = argc > 5 ? atoi(argv[5]) : 0;
+    constexpr int C = 9;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device %s, %d CUs, n=%llu, c=%d, column=%s\n", prop.gcnArchName, cus, (unsigned long long)n, C,
+           column ? "random" : "mod5");
+
+    const size_t pbytes = (n * C + 7) / 8 + 256;
+    uint8_t *packed, *bitmap;
+    unsigned long long *hits;
+    uint32_t *sink;
+    CK(hipMalloc(&packed, pbytes));
+    CK(hipMalloc(&bitmap, n / 8 + 4096));
+    CK(hipMalloc(&hits, 64));
+    unsigned long long *scratch;
+    CK(hipMalloc(&scratch, (kScratchDone + 8) * 8));
+    CK(hipMemset(scratch, 0, (kScratchDone + 8) * 8));
+    CK(hipMalloc(&sink, 64));
+    PackArgs pa{};
+    pa.n = n;
+    pa.first_row = 0;
+    pa.param = column ? 42 : 5;
+    pa.out = (uint32_t *)packed;
+    pa.out_dwords = pbytes / 4;
+    pa.c = C;
+    if (column)
+        hipLaunchKernelGGL(pack_kernel<kSrcSplitmix>, dim3(cus * 8), dim3(256), 0, 0, pa);
+    else
+        hipLaunchKernelGGL(pack_kernel<kSrcMod>, dim3(cus * 8), dim3(256), 0, 0, pa);
+    CK(hipDeviceSynchronize());
+
+    ScanArgs sa{};
+    sa.packed = packed;
+    sa.n = n;
+    sa.out = bitmap;
+    sa.out_stride = 0;
+    sa.hits = NOHITS ? nullptr : hits;
+    sa.scratch = scratch;
+    sa.key[0] = 3;
+    sa.nkeys = 1;
+
+    std::vector<Variant> vs;
+    const double scan_bytes = n * C / 8.0 + n / 8.0;
+    const double read_bytes = n * C / 8.0;
+#define SCAN_VARIANT(NAME, VPL, AUX, ABL, BYTES)                                                                        \
+    vs.push_back({NAME,                                                                                                \
+                  [=](int bpc, hipStream_t s) {                                                                        \
+                      using G = ScanGeom<C, VPL>;                                                                      \
+                      uint64_t ntiles = (n + G::TILE_VALUES - 1) / G::TILE_VALUES;                                     \
+                      uint64_t want = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;                                  \
+                      unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)bpc * cus);                         \
+                      hipLaunchKernelGGL((scan_kernel<C, kModeEq, AUX, VPL, ABL>), dim3(grid), dim3(kBlockThreads), 0, \
+                                         s, sa);                                                                       \
+                  },                                                                                                   \
+                  ScanGeom<C, VPL>::OCC, BYTES, (ABL) == 0 || (ABL) == 3})
+    SCAN_VARIANT("vpl128 aux0", 128, 0, 0, scan_bytes);
+    SCAN_VARIANT("vpl128 nt", 128, 2, 0, scan_bytes);
+    SCAN_VARIANT("vpl64 aux0", 64, 0, 0, scan_bytes);
+    SCAN_VARIANT("vpl64 nt", 64, 2, 0, scan_bytes);
+    SCAN_VARIANT("vpl32 nt", 32, 2, 0, scan_bytes);
+    SCAN_VARIANT("vpl128 nt ABL1 dma-only", 128, 2, 1, read_bytes);
+    SCAN_VARIANT("vpl128 nt ABL2 dma+lds", 128, 2, 2, read_bytes);
+    SCAN_VARIANT("vpl128 nt ABL3 no-store", 128, 2, 3, read_bytes);
+    SCAN_VARIANT("vpl64 nt ABL1 dma-only", 64, 2, 1, read_bytes);
+    SCAN_VARIANT("vpl64 nt ABL3 no-store", 64, 2, 3, read_bytes);
+    const uint64_t nvec = (n * C / 8) / 16;
+    vs.push_back({"read x4 unroll4", [=](int bpc, hipStream_t s) {
+                      hipLaunchKernelGGL((read_kernel<4, 0>), dim3(bpc * cus), dim3(256), 0, s, (const u32x4 *)packed, nvec, sink);
+                  }, 8, read_bytes, false});
+    vs.push_back({"read x4 unroll4 nt", [=](int bpc, hipStream_t s) {
+                      hipLaunchKernelGGL((read_kernel<4, 1>), dim3(bpc * cus), dim3(256), 0, s, (const u32x4 *)packed, nvec, sink);
+                  }, 8, read_bytes, false});
+    vs.push_back({"read x4 unroll8 nt", [=](int bpc, hipStream_t s) {
+                      hipLaunchKernelGGL((read_kernel<8, 1>), dim3(bpc * cus), dim3(256), 0, s, (const u32x4 *)packed, nvec, sink);
+                  }, 8, read_bytes, false});
+
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    struct Cfg {
+        int v, bpc;
+        std::vector<float> ms;
+        unsigned long long hits;
+    };
+    std::vector<Cfg> cfgs;
+    for (int v = 0; v < (int)vs.size(); v++)
+        for (int bpc : {1, 2, 3, 4, 6, 8})
+            if (bpc <= vs[v].max_bpc) cfgs.push_back({v, bpc, {}, 0});
+    // warm-up + correctness
+    for (auto &c : cfgs) {
+        CK(hipMemsetAsync(hits, 0, 8, 0));
+        vs[c.v].launch(c.bpc, 0);
+        CK(hipMemcpy(&c.hits, hits, 8, hipMemcpyDeviceToHost));
+        CK(hipGetLastError());
+    }
+    for (int r = 0; r < REPS; r++) {
+        for (auto &c : cfgs) {
+            CK(hipMemsetAsync(hits, 0, 8, 0));
+            CK(hipEventRecord(e0, 0));
+            vs[c.v].launch(c.bpc, 0);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            c.ms.push_back(ms);
+        }
+    }
+    const unsigned long long ref_hits = cfgs[0].hits;
+    printf("%-28s %4s %9s %9s %10s %10s  %s\n", "variant", "bpc", "med ms", "min ms", "GB/s(med)", "GB/s(min)", "hits");
+    for (auto &c : cfgs) {
+        std::sort(c.ms.begin(), c.ms.end());
+        float med = c.ms[c.ms.size() / 2], mn = c.ms[0];
+        const Variant &v = vs[c.v];
+        printf("%-28s %4d %9.4f %9.4f %10.1f %10.1f  %s\n", v.name.c_str(), c.bpc, med, mn, v.bytes / med / 1e6,
+               v.bytes / mn / 1e6, !v.counts_hits ? "-" : (c.hits == ref_hits ? "ok" : "MISMATCH"));
+    }
+    printf("reference hits = %llu\n", ref_hits);
+    // sustained mode: BURST launches back to back, no host sync in between (what bench.py times)
+    const int BURST = 100;
+    printf("\n%-28s %4s %12s %10s   (burst of %d launches back to back)\n", "variant", "bpc", "ms/launch", "GB/s", BURST);
+    for (auto &c : cfgs) {
+        const Variant &v = vs[c.v];
+        if (v.name.find("ABL") != std::string::npos && v.name.find("ABL1") == std::string::npos) continue;
+        for (int i = 0; i < 5; i++) v.launch(c.bpc, 0);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < BURST; i++) v.launch(c.bpc, 0);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= BURST;
+        printf("%-28s %4d %12.4f %10.1f\n", v.name.c_str(), c.bpc, ms, v.bytes / ms / 1e6);
+    }
+    return 0;
+}
