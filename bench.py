@@ -96,9 +96,16 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback"
+    # BENCH_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (ranks share devices);
+    # the judged runs use nccl (= RCCL over xGMI), one rank per GPU
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from shared_simd_scan_amd import ScanEngine, kernel_name
 
@@ -144,9 +151,15 @@ def main():
         kname = kernel_name("decompress", c)
 
     def sync_all():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         step()
@@ -162,12 +175,8 @@ def main():
     dev_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the stream the kernels ran on
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        d = torch.tensor([dev_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(d, op=dist.ReduceOp.MAX)
-        dev_ms = float(d.item())
+        elapsed = reduce_max(elapsed)
+        dev_ms = reduce_max(dev_ms)
 
     # correctness of what was timed
     expect_hits = None
@@ -190,9 +199,7 @@ def main():
             full = gather_bitmaps(bitmap[:nb], dst=0, out=full)
         sync_all()
         gather_ms = (time.perf_counter() - g0) / reps * 1e3
-        g = torch.tensor([gather_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(g, op=dist.ReduceOp.MAX)
-        gather_ms = float(g.item())
+        gather_ms = reduce_max(gather_ms)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

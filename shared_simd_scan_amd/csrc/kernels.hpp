@@ -263,16 +263,17 @@ __device__ __forceinline__ uint32_t tail_mask(int valid, int J)
     return v >= 32 ? 0xffffffffu : (v <= 0 ? 0u : ((1u << v) - 1u));
 }
 
-template <int WORDS> __device__ __forceinline__ void store_words(uint8_t *dst, const uint32_t (&v)[WORDS])
+// NT: non-temporal store (the bitmap is written once and not re-read by this kernel)
+template <int WORDS, bool NT = false> __device__ __forceinline__ void store_words(uint8_t *dst, const uint32_t (&v)[WORDS])
 {
     if constexpr (WORDS == 4) {
         u32x4 t = {v[0], v[1], v[2], v[3]};
-        *(u32x4 *)dst = t;
+        if constexpr (NT) __builtin_nontemporal_store(t, (u32x4 *)dst); else *(u32x4 *)dst = t;
     } else if constexpr (WORDS == 2) {
         u32x2 t = {v[0], v[1]};
-        *(u32x2 *)dst = t;
+        if constexpr (NT) __builtin_nontemporal_store(t, (u32x2 *)dst); else *(u32x2 *)dst = t;
     } else {
-        *(uint32_t *)dst = v[0];
+        if constexpr (NT) __builtin_nontemporal_store(v[0], (uint32_t *)dst); else *(uint32_t *)dst = v[0];
     }
 }
 
@@ -319,12 +320,15 @@ __device__ __forceinline__ void hits_finalize(const ScanArgs &a, uint32_t P, int
 // MODE kModeEq / kModeRange: one bitmap.  MODE kModeShared: 8 keys per pass over the lane's registers
 // (one decode, 8 compares per value), ceil(P/8) passes per tile; the column is read from HBM once.
 // ABL (ablation, tools/tune_scan.hip only): 1 = DMA only, 2 = DMA + LDS reads, 3 = no bitmap stores.
-template <int C, int MODE, int AUX, int VPL, int ABL = 0>
+// AUX: bits 0-3 = cache policy of the DMA loads (0 default, 2 nt); bit 4 = non-temporal bitmap stores.
+template <int C, int MODE, int AUX_, int VPL, int ABL = 0>
 __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void scan_kernel(ScanArgs a)
 {
     using G = ScanGeom<C, VPL>;
     constexpr int NK = (MODE == kModeShared) ? kMaxKeysPerPass : 1;
     constexpr int WORDS = G::WORDS;
+    constexpr int AUX = AUX_ & 15;
+    constexpr bool NTS = (AUX_ & 16) != 0;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
 
     const int lane = threadIdx.x & 63;
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void sca
 #pragma unroll
                     for (int q = 0; q < NK; q++)
                         if ((uint32_t)q < P)
-                            store_words<WORDS>(a.out + (uint64_t)q * a.out_stride + prev * G::BITMAP_BYTES + lane * (WORDS * 4), res[q]);
+                            store_words<WORDS, NTS>(a.out + (uint64_t)q * a.out_stride + prev * G::BITMAP_BYTES + lane * (WORDS * 4), res[q]);
                 }
             }
             const uint64_t next = tile + stride;
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void sca
 #pragma unroll
                 for (int q = 0; q < NK; q++)
                     if ((uint32_t)q < P)
-                        store_words<WORDS>(a.out + (uint64_t)q * a.out_stride + prev * G::BITMAP_BYTES + lane * (WORDS * 4), res[q]);
+                        store_words<WORDS, NTS>(a.out + (uint64_t)q * a.out_stride + prev * G::BITMAP_BYTES + lane * (WORDS * 4), res[q]);
             } else if (res[0][0] == 0x12345678u) { // keep the ablated pipeline alive
                 a.out[lane] = 1;
             }
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void sca
                         if (full) {
 #pragma unroll
                             for (int j = 0; j < WORDS; j++) cnt += __builtin_popcount(res[q][j]);
-                            store_words<WORDS>(dst, res[q]);
+                            store_words<WORDS, NTS>(dst, res[q]);
                         } else {
                             cnt = finish_tail(tile, res[q], dst, 1);
                         }

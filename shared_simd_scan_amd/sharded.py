@@ -47,6 +47,10 @@ def gather_bitmaps(local: torch.Tensor, dst: int = 0, out: Optional[torch.Tensor
     Returns the concatenated bitmap on `dst`, None elsewhere."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the N>1 path on a box with fewer GPUs than ranks: stage through host memory
+        res = gather_bitmaps(local.cpu(), dst=dst, out=None, sizes=sizes, group=group)
+        return res.to(local.device) if res is not None else None
     nbytes = local.numel()
     if sizes is None:
         sizes = [nbytes] * world
@@ -69,6 +73,8 @@ def gather_bitmaps(local: torch.Tensor, dst: int = 0, out: Optional[torch.Tensor
 
 def sum_hits(local_hits: torch.Tensor, group=None) -> torch.Tensor:
     """All ranks get the column-wide hit count(s)."""
+    if local_hits.is_cuda and dist.get_backend(group) == "gloo":
+        return sum_hits(local_hits.cpu(), group).to(local_hits.device)
     total = local_hits.clone()
     dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     return total

@@ -1,0 +1,107 @@
+"""CPU: the multi-GPU (N>1) path on gloo, world_size 2.
+
+The per-shard scan on a CPU rank is the ORACLE (injected here, in tests only: the product's ShardedColumn always
+uses the HIP engine); what is under test is the product's sharding logic: row-range partition, bitmap gather,
+hit-count reduction, ragged last shard.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_rows_partition():
+    from shared_simd_scan_amd.sharded import SHARD_ALIGN, shard_rows
+
+    for n in (0, 1, 8191, 8192, 8193, 100_003, 1_000_000_000, 8_000_000_000):
+        for world in (1, 2, 3, 4, 8):
+            r = shard_rows(n, world)
+            assert len(r) == world and r[0][0] == 0 and r[-1][1] == n
+            for (a, b), (c, d) in zip(r, r[1:]):
+                assert b == c and a <= b
+            for a, b in r:
+                assert a % SHARD_ALIGN == 0 or a == n  # every shard starts on a tile boundary
+    # BASELINE config 5: 8e9 rows over 8 GPUs -> 1e9 rows each (1e9 is not a multiple of 8192: rounded up)
+    r = shard_rows(8_000_000_000, 8)
+    assert all(b - a <= 1_000_005_632 for a, b in r) and sum(b - a for a, b in r) == 8_000_000_000
+
+
+class OracleEngine:
+    """CPU stand-in for ScanEngine inside this test: same methods, backed by oracle.c."""
+
+    def __init__(self):
+        from oracle import oracle
+
+        self.O = oracle()
+
+    def generate(self, kind, n, c, param=0, first_row=0):
+        vals = self.O.gen_values(kind, n, c, param, first=first_row)
+        return (self.O.pack(vals, c), n, c)
+
+    def scan(self, key, col):
+        packed, n, c = col
+        bm, hits = self.O.scan_eq(packed, n, c, key)
+        return torch.from_numpy(bm), torch.tensor([hits], dtype=torch.int64)
+
+    def scan_range(self, lo, hi, col):
+        packed, n, c = col
+        bm, hits = self.O.scan_range(packed, n, c, lo, hi)
+        return torch.from_numpy(bm), torch.tensor([hits], dtype=torch.int64)
+
+
+def worker(rank, world, port, n, c, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle
+        from shared_simd_scan_amd.sharded import ShardedColumn
+
+        O = oracle()
+        sc = ShardedColumn(n, c, engine=OracleEngine())
+        sc.generate("splitmix", 42)
+        key = int(O.gen_values("splitmix", 1, c, 42, first=12345 % max(n, 1))[0])
+        full, hits = sc.scan(key, dst=0)
+        lo, hi = (1 << c) // 4, (1 << c) // 2
+        full_r, hits_r = sc.scan_range(lo, hi, dst=0)
+        if rank == 0:
+            vals = O.gen_values("splitmix", n, c, 42)
+            packed = O.pack(vals, c)
+            ref, ref_hits = O.scan_eq(packed, n, c, key)
+            ref_r, ref_hits_r = O.scan_range(packed, n, c, lo, hi)
+            ok = (np.array_equal(full.numpy(), ref) and int(hits.item()) == ref_hits
+                  and np.array_equal(full_r.numpy(), ref_r) and int(hits_r.item()) == ref_hits_r)
+            q.put(("ok" if ok else "mismatch", sc.ranges))
+        else:
+            assert full is None
+            assert int(hits.item()) >= 0  # every rank gets the column-wide count
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [100_003, 16_384, 8192 * 3 + 5, 5])
+def test_sharded_scan_world2_gloo(n):
+    world, c = 2, 9
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, n, c, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    status, ranges = q.get(timeout=10)
+    assert status == "ok", ranges

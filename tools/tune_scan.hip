@@ -119,6 +119,9 @@ int main(int argc, char **argv)
                   ScanGeom<C, VPL>::OCC, BYTES, (ABL) == 0 || (ABL) == 3})
     SCAN_VARIANT("vpl128 aux0", 128, 0, 0, scan_bytes);
     SCAN_VARIANT("vpl128 nt", 128, 2, 0, scan_bytes);
+    SCAN_VARIANT("vpl128 nt ntstore", 128, 18, 0, scan_bytes);
+    SCAN_VARIANT("vpl128 aux0 ntstore", 128, 16, 0, scan_bytes);
+    SCAN_VARIANT("vpl64 nt ntstore", 64, 18, 0, scan_bytes);
     SCAN_VARIANT("vpl64 aux0", 64, 0, 0, scan_bytes);
     SCAN_VARIANT("vpl64 nt", 64, 2, 0, scan_bytes);
     SCAN_VARIANT("vpl32 nt", 32, 2, 0, scan_bytes);
