@@ -27,7 +27,7 @@ struct mi355_ctx {
     int max_blocks_per_cu = 0;
     int dma_aux = 2; // non-temporal HBM->LDS loads: the column is streamed once
     unsigned long long *hits_scratch = nullptr; // host-pointer API: where the kernels deliver hit counts
-    unsigned long long *kernel_scratch = nullptr; // kScratchDone+1 words, all zero between launches (kernels.hpp hits_finalize)
+    unsigned long long *kernel_scratch = nullptr; // kScratchWords words, all zero between launches (kernels.hpp hits_finalize)
     int32_t *keys_scratch = nullptr;            // 1024 + 8 keys
 };
 
@@ -140,8 +140,8 @@ int mi355_ctx_create(int device, void *hip_stream, mi355_ctx **out)
     if (const char *s = getenv("MI355_MAX_BLOCKS_PER_CU")) c->max_blocks_per_cu = atoi(s);
     if (const char *s = getenv("MI355_DMA_AUX")) c->dma_aux = atoi(s);
     hipError_t e = hipMalloc((void **)&c->hits_scratch, kMaxKeys * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->kernel_scratch, (kScratchDone + 8) * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(c->kernel_scratch, 0, (kScratchDone + 8) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->kernel_scratch, kScratchWords * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(c->kernel_scratch, 0, kScratchWords * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&c->keys_scratch, (kMaxKeys + 8) * sizeof(int32_t));
     if (e != hipSuccess) {
         delete c;
@@ -426,6 +426,7 @@ int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n,
     if (P <= (unsigned)kMaxKeysPerPass) {
         for (unsigned q = 0; q < (unsigned)kMaxKeysPerPass; q++) r.scan.key[q] = (uint32_t)keys_host[q < P ? q : P - 1];
     } else {
+        // (a copy through pageable host memory: hipMemcpyAsync + sync costs ~20 us, paid only for P > 8)
         // keys travel through device memory, padded to a multiple of 8 with copies of the last key
         std::vector<int32_t> padded((P + 7) / 8 * 8, keys_host[P - 1]);
         memcpy(padded.data(), keys_host, P * sizeof(int32_t));
@@ -554,7 +555,7 @@ const char *mi355_kernel_name(const char *op, unsigned c)
     else if (!strcmp(op, "scan_range"))
         snprintf(buf, sizeof buf, "mi355::scan_kernel<%u, 1, ", c);
     else if (!strcmp(op, "shared_scan"))
-        snprintf(buf, sizeof buf, "mi355::scan_kernel<%u, 2, ", c);
+        snprintf(buf, sizeof buf, "mi355::shared_lut_kernel<%u, ", c);
     else if (!strcmp(op, "decompress"))
         snprintf(buf, sizeof buf, "mi355::decompress_kernel<%u, ", c);
     else if (!strcmp(op, "pack"))

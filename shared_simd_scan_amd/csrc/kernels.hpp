@@ -31,7 +31,6 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = kWavesPerBlock * 64;
 constexpr int kMaxKeysPerPass = 8;
 constexpr int kMaxKeys = 1024;      // what the reference's linear_simple tops out at (src/simd_scan_shared_linear.cpp:78)
-constexpr int kScratchDone = kMaxKeys; // index of the "waves finished" counter in the scratch array
 
 // ---- tile geometry of the scan kernels -----------------------------------------------------
 // A wave owns a tile of 64*VPL consecutive values; lane l owns values [l*VPL, (l+1)*VPL) of it,
@@ -49,7 +48,7 @@ template <int C, int VPL> struct ScanGeom {
     static constexpr int BITMAP_BYTES = TILE_VALUES / 8;
     // waves per SIMD the LDS footprint admits (160 KiB per CU, 4 waves per block), capped at 8:
     // the register allocator is told to aim for that
-    static constexpr int OCC_LDS = (160 * 1024) / (4 * LDS_BYTES);
+    static constexpr int OCC_LDS = (160 * 1024) / (4 * LDS_BYTES + 64); // +64: the block's ticket word
     static constexpr int OCC = OCC_LDS >= 8 ? 8 : (OCC_LDS < 1 ? 1 : OCC_LDS);
 };
 
@@ -76,7 +75,7 @@ struct ScanArgs {
     uint8_t *out;              // bitmap(s)
     uint64_t out_stride;       // bytes between per-predicate bitmaps (kModeShared, layout 0)
     unsigned long long *hits;  // device counters (one per key), OVERWRITTEN with the totals; may be null
-    unsigned long long *scratch; // context scratch: kScratchDone+1 words, all zero between launches
+    unsigned long long *scratch; // context scratch: kScratchWords words, all zero between launches
     const int32_t *keys_dev;   // kModeShared with P > kMaxKeysPerPass: device key array (padded to 8)
     uint32_t key[kMaxKeysPerPass]; // kModeEq: key[0]; kModeRange: key[0]=lo, key[1]=hi-lo; kModeShared: P<=8 keys
     uint32_t nkeys;            // P
@@ -134,89 +133,172 @@ template <int C, int K, int NW> __device__ __forceinline__ uint32_t extract(cons
     }
 }
 
-// acc = 2*acc + (x == key).  v_cmp writes VCC, v_addc_co_u32 shifts the accumulator left by adding
-// it to itself and takes the compare bit as carry-in: one VALU op per result bit.
-__device__ __forceinline__ void push_eq(uint32_t &acc, uint32_t x, uint32_t key)
-{
-    asm("v_cmp_eq_u32_e32 vcc, %2, %1\n\t"
-        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
-        : "+v"(acc)
-        : "v"(x), "s"(key)
-        : "vcc");
-}
+// ---- compare + append one result bit:  acc = 2*acc + predicate(x) ---------------------------------
+// v_cmp writes a lane mask, v_addc_co_u32 adds the accumulator to itself (a left shift) with that mask as
+// carry-in: two VALU ops per result bit.  A v_cmp -> v_addc pair through ONE mask register is a dependent
+// chain (measured ~10 cycles per instruction with 2 waves per SIMD), so the helpers below always run several
+// independent chains side by side -- N compares into N different SGPR pairs, then the N add-with-carry --
+// which also keeps every VALU-written SGPR at least N instructions away from the VALU that reads it
+// (gfx950 wants 2 wait states there; hipcc does not look inside an asm statement).
 
-// the same for 8 keys against one value, as ONE asm statement (between separate asm statements that
-// clobber VCC hipcc inserts an s_nop per pair)
+// one value against 8 keys (shared scan)
 __device__ __forceinline__ void push_eq8(uint32_t (&acc)[8], uint32_t x, const uint32_t (&key)[kMaxKeysPerPass])
 {
-    asm("v_cmp_eq_u32_e32 vcc, %9, %8\n\t"
-        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
-        "v_cmp_eq_u32_e32 vcc, %10, %8\n\t"
-        "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\t"
-        "v_cmp_eq_u32_e32 vcc, %11, %8\n\t"
-        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc\n\t"
-        "v_cmp_eq_u32_e32 vcc, %12, %8\n\t"
-        "v_addc_co_u32_e32 %3, vcc, %3, %3, vcc\n\t"
-        "v_cmp_eq_u32_e32 vcc, %13, %8\n\t"
-        "v_addc_co_u32_e32 %4, vcc, %4, %4, vcc\n\t"
-        "v_cmp_eq_u32_e32 vcc, %14, %8\n\t"
-        "v_addc_co_u32_e32 %5, vcc, %5, %5, vcc\n\t"
-        "v_cmp_eq_u32_e32 vcc, %15, %8\n\t"
-        "v_addc_co_u32_e32 %6, vcc, %6, %6, vcc\n\t"
-        "v_cmp_eq_u32_e32 vcc, %16, %8\n\t"
-        "v_addc_co_u32_e32 %7, vcc, %7, %7, vcc"
-        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
-        : "v"(x), "s"(key[0]), "s"(key[1]), "s"(key[2]), "s"(key[3]), "s"(key[4]), "s"(key[5]), "s"(key[6]), "s"(key[7])
-        : "vcc");
+    unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+    asm("v_cmp_eq_u32_e64 %8, %17, %16\n\t"
+        "v_cmp_eq_u32_e64 %9, %18, %16\n\t"
+        "v_cmp_eq_u32_e64 %10, %19, %16\n\t"
+        "v_cmp_eq_u32_e64 %11, %20, %16\n\t"
+        "v_cmp_eq_u32_e64 %12, %21, %16\n\t"
+        "v_cmp_eq_u32_e64 %13, %22, %16\n\t"
+        "v_cmp_eq_u32_e64 %14, %23, %16\n\t"
+        "v_cmp_eq_u32_e64 %15, %24, %16\n\t"
+        "v_addc_co_u32_e64 %0, %8, %0, %0, %8\n\t"
+        "v_addc_co_u32_e64 %1, %9, %1, %1, %9\n\t"
+        "v_addc_co_u32_e64 %2, %10, %2, %2, %10\n\t"
+        "v_addc_co_u32_e64 %3, %11, %3, %3, %11\n\t"
+        "v_addc_co_u32_e64 %4, %12, %4, %4, %12\n\t"
+        "v_addc_co_u32_e64 %5, %13, %5, %5, %13\n\t"
+        "v_addc_co_u32_e64 %6, %14, %6, %6, %14\n\t"
+        "v_addc_co_u32_e64 %7, %15, %7, %7, %15"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+          "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
+        : "v"(x), "s"(key[0]), "s"(key[1]), "s"(key[2]), "s"(key[3]), "s"(key[4]), "s"(key[5]), "s"(key[6]), "s"(key[7]));
 }
 
-// acc = 2*acc + (x - lo <= span)   (unsigned: lo <= x <= lo+span)
-__device__ __forceinline__ void push_range(uint32_t &acc, uint32_t x, uint32_t lo, uint32_t span)
+// N values (one per bitmap word of the lane) against one key / one range
+template <int MODE> __device__ __forceinline__ void push1(uint32_t &a0, uint32_t x0, uint32_t k0, uint32_t k1)
 {
-    uint32_t t;
-    asm("v_subrev_u32_e32 %1, %3, %2\n\t"
-        "v_cmp_ge_u32_e32 vcc, %4, %1\n\t"
-        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
-        : "+v"(acc), "=&v"(t)
-        : "v"(x), "s"(lo), "s"(span)
-        : "vcc");
-}
-
-template <int C, int J, int K, int NK, int MODE, int NW>
-__device__ __forceinline__ void decode_step(const uint32_t (&w)[NW], uint32_t (&acc)[NK], const uint32_t (&key)[kMaxKeysPerPass])
-{
-    // values are pushed from the highest index of the 32-group down to the lowest, so that after
-    // 32 pushes value 32J+0 sits in bit 0 (src/util.cpp:51-58 bit order)
-    uint32_t x = extract<C, 32 * J + K, NW>(w);
-    if constexpr (MODE == kModeRange) {
-        push_range(acc[0], x, key[0], key[1]);
-    } else if constexpr (NK == 8) {
-        push_eq8(acc, x, key);
+    if constexpr (MODE == 1) {
+        uint32_t t;
+        asm("v_subrev_u32_e32 %1, %3, %2\n\t"
+            "v_cmp_ge_u32_e32 vcc, %4, %1\n\t"
+            "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+            : "+v"(a0), "=&v"(t)
+            : "v"(x0), "s"(k0), "s"(k1)
+            : "vcc");
     } else {
-#pragma unroll
-        for (int q = 0; q < NK; q++) push_eq(acc[q], x, key[q]);
+        asm("v_cmp_eq_u32_e32 vcc, %2, %1\n\t"
+            "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+            : "+v"(a0)
+            : "v"(x0), "s"(k0)
+            : "vcc");
     }
-    if constexpr (K > 0) decode_step<C, J, K - 1, NK, MODE, NW>(w, acc, key);
 }
 
-// bitmap word J (values 32J..32J+31 of the lane) for each of NK predicates
-template <int C, int J, int NK, int MODE, int NW>
-__device__ __forceinline__ void decode_word(const uint32_t (&w)[NW], uint32_t (&acc)[NK], const uint32_t (&key)[kMaxKeysPerPass])
+template <int MODE>
+__device__ __forceinline__ void push2(uint32_t &a0, uint32_t &a1, uint32_t x0, uint32_t x1, uint32_t k0, uint32_t k1)
 {
+    unsigned long long m0, m1;
+    if constexpr (MODE == 1) {
+        uint32_t t0, t1;
+        asm("v_subrev_u32_e32 %4, %8, %6\n\t"
+            "v_subrev_u32_e32 %5, %8, %7\n\t"
+            "v_cmp_ge_u32_e64 %2, %9, %4\n\t"
+            "v_cmp_ge_u32_e64 %3, %9, %5\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\t"
+            "v_addc_co_u32_e64 %1, %3, %1, %1, %3"
+            : "+v"(a0), "+v"(a1), "=&s"(m0), "=&s"(m1), "=&v"(t0), "=&v"(t1)
+            : "v"(x0), "v"(x1), "s"(k0), "s"(k1));
+    } else {
+        asm("v_cmp_eq_u32_e64 %2, %6, %4\n\t"
+            "v_cmp_eq_u32_e64 %3, %6, %5\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\t"
+            "v_addc_co_u32_e64 %1, %3, %1, %1, %3"
+            : "+v"(a0), "+v"(a1), "=&s"(m0), "=&s"(m1)
+            : "v"(x0), "v"(x1), "s"(k0));
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void push4(uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t &a3, uint32_t x0, uint32_t x1,
+                                      uint32_t x2, uint32_t x3, uint32_t k0, uint32_t k1)
+{
+    unsigned long long m0, m1, m2, m3;
+    if constexpr (MODE == 1) {
+        uint32_t t0, t1, t2, t3;
+        asm("v_subrev_u32_e32 %8, %16, %12\n\t"
+            "v_subrev_u32_e32 %9, %16, %13\n\t"
+            "v_subrev_u32_e32 %10, %16, %14\n\t"
+            "v_subrev_u32_e32 %11, %16, %15\n\t"
+            "v_cmp_ge_u32_e64 %4, %17, %8\n\t"
+            "v_cmp_ge_u32_e64 %5, %17, %9\n\t"
+            "v_cmp_ge_u32_e64 %6, %17, %10\n\t"
+            "v_cmp_ge_u32_e64 %7, %17, %11\n\t"
+            "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\t"
+            "v_addc_co_u32_e64 %1, %5, %1, %1, %5\n\t"
+            "v_addc_co_u32_e64 %2, %6, %2, %2, %6\n\t"
+            "v_addc_co_u32_e64 %3, %7, %3, %3, %7"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&v"(t0), "=&v"(t1),
+              "=&v"(t2), "=&v"(t3)
+            : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(k0), "s"(k1));
+    } else {
+        asm("v_cmp_eq_u32_e64 %4, %12, %8\n\t"
+            "v_cmp_eq_u32_e64 %5, %12, %9\n\t"
+            "v_cmp_eq_u32_e64 %6, %12, %10\n\t"
+            "v_cmp_eq_u32_e64 %7, %12, %11\n\t"
+            "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\t"
+            "v_addc_co_u32_e64 %1, %5, %1, %1, %5\n\t"
+            "v_addc_co_u32_e64 %2, %6, %2, %2, %6\n\t"
+            "v_addc_co_u32_e64 %3, %7, %3, %3, %7"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+            : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(k0));
+    }
+}
+
+// ---- decode a lane's run ------------------------------------------------------------------------------
+// Values are pushed from the highest index of each 32-group down to the lowest, so that after 32 pushes value
+// 32J+0 sits in bit 0 (src/util.cpp:51-58 bit order).
+
+// single predicate: step K handles value 32J+K of every bitmap word J of the lane at once
+template <int C, int VPL, int K, int MODE, int NW>
+__device__ __forceinline__ void decode_step1(const uint32_t (&w)[NW], uint32_t (&res)[1][VPL / 32], uint32_t k0, uint32_t k1)
+{
+    if constexpr (VPL == 128) {
+        push4<MODE>(res[0][0], res[0][1], res[0][2], res[0][3], extract<C, K, NW>(w), extract<C, 32 + K, NW>(w),
+                    extract<C, 64 + K, NW>(w), extract<C, 96 + K, NW>(w), k0, k1);
+    } else if constexpr (VPL == 64) {
+        push2<MODE>(res[0][0], res[0][1], extract<C, K, NW>(w), extract<C, 32 + K, NW>(w), k0, k1);
+    } else {
+        push1<MODE>(res[0][0], extract<C, K, NW>(w), k0, k1);
+    }
+    if constexpr (K > 0) decode_step1<C, VPL, K - 1, MODE, NW>(w, res, k0, k1);
+}
+
+// 8 predicates: one value at a time against the 8 keys
+template <int C, int J, int K, int NW>
+__device__ __forceinline__ void decode_step8(const uint32_t (&w)[NW], uint32_t (&acc)[8], const uint32_t (&key)[kMaxKeysPerPass])
+{
+    push_eq8(acc, extract<C, 32 * J + K, NW>(w), key);
+    if constexpr (K > 0) decode_step8<C, J, K - 1, NW>(w, acc, key);
+}
+
+template <int C, int VPL, int J, int NW>
+__device__ __forceinline__ void decode_words8(const uint32_t (&w)[NW], uint32_t (&res)[8][VPL / 32],
+                                              const uint32_t (&key)[kMaxKeysPerPass])
+{
+    uint32_t acc[8];
 #pragma unroll
-    for (int q = 0; q < NK; q++) acc[q] = 0;
-    decode_step<C, J, 31, NK, MODE, NW>(w, acc, key);
+    for (int q = 0; q < 8; q++) acc[q] = 0;
+    decode_step8<C, J, 31, NW>(w, acc, key);
+#pragma unroll
+    for (int q = 0; q < 8; q++) res[q][J] = acc[q];
+    if constexpr (J + 1 < VPL / 32) decode_words8<C, VPL, J + 1, NW>(w, res, key);
 }
 
 template <int C, int VPL, int J, int NK, int MODE, int NW>
 __device__ __forceinline__ void decode_words(const uint32_t (&w)[NW], uint32_t (&res)[NK][VPL / 32],
                                              const uint32_t (&key)[kMaxKeysPerPass])
 {
-    uint32_t acc[NK];
-    decode_word<C, J, NK, MODE, NW>(w, acc, key);
+    if constexpr (NK == 8) {
+        decode_words8<C, VPL, 0, NW>(w, res, key);
+    } else {
 #pragma unroll
-    for (int q = 0; q < NK; q++) res[q][J] = acc[q];
-    if constexpr (J + 1 < VPL / 32) decode_words<C, VPL, J + 1, NK, MODE, NW>(w, res, key);
+        for (int j = 0; j < VPL / 32; j++) res[0][j] = 0;
+        decode_step1<C, VPL, 31, MODE, NW>(w, res, key[0], key[1]);
+    }
 }
 
 // lane-local packed data: LDS -> VGPRs (ds_read_b128 / b64 / b32 by VPL)
@@ -278,33 +360,46 @@ template <int WORDS, bool NT = false> __device__ __forceinline__ void store_word
 }
 
 // ---- hit counts without a memset launch ---------------------------------------------------------
-// Every wave adds its per-key counts to the context's scratch totals, waits until those adds have been
-// performed, then takes a ticket on the "done" counter.  All of these are device-scope atomic RMWs, which
-// gfx950 executes at the memory side (coherent across the 8 XCDs, never held in a CU's L1 or an XCD's L2),
-// so no cache write-back / invalidate is needed -- a per-wave agent-scope release fence (buffer_wbl2) here
-// cost 25 % of the kernel when launches run back to back.  The wave that draws the last ticket therefore
-// sees every other wave's adds: it moves the totals to the caller's `hits` array with atomic exchanges that
-// also zero the scratch for the next launch.  One kernel launch per scan.
+// Same-address device atomics serialise at ~12 ns each on MI355X, so 4096 waves x 8 keys adding into 8 words
+// cost ~0.4 ms at the tail of a shared scan.  Counts therefore go to kHitSlots replicas of the totals (slot =
+// block index mod kHitSlots, rows 8 KiB apart so replicas never share a line): each address sees only
+// (#waves / kHitSlots) adds.  Completion is detected per BLOCK: every wave drains its adds (vmcnt counts
+// atomics), the block barriers, one lane takes a ticket on the "done" counter.  All of these are device-scope
+// atomic RMWs, which gfx950 executes at the memory side (coherent across the 8 XCDs, never held in a CU's L1
+// or an XCD's L2), so no cache write-back / invalidate is needed -- a per-wave agent-scope release fence
+// (buffer_wbl2) here cost 25 % of the kernel when launches ran back to back.  The block that draws the last
+// ticket sums the replicas into the caller's `hits` array with atomic exchanges that also zero the scratch
+// for the next launch.  One kernel launch per scan.
+constexpr int kHitSlots = 64;
+constexpr int kScratchWords = kHitSlots * kMaxKeys + 8; // replicas + "done" counter (+ diagnostics)
+constexpr int kScratchDone = kHitSlots * kMaxKeys;
+
 __device__ __forceinline__ void hits_add(const ScanArgs &a, uint32_t k, uint32_t wave_total, int lane)
 {
     if (lane == 0 && wave_total)
-        __hip_atomic_fetch_add(a.scratch + k, (unsigned long long)wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.scratch + (blockIdx.x % kHitSlots) * kMaxKeys + k, (unsigned long long)wave_total,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// every thread of the block must call this (it contains a block barrier)
 __device__ __forceinline__ void hits_finalize(const ScanArgs &a, uint32_t P, int lane)
 {
     if (!a.hits) return;
-    unsigned long long ticket = 0;
-    // this wave's adds are complete (vmcnt counts atomics) before its ticket is drawn
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0)
-        ticket = __hip_atomic_fetch_add(a.scratch + kScratchDone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ticket = __shfl(ticket, 0, 64);
-    const unsigned long long nwaves = (unsigned long long)gridDim.x * kWavesPerBlock;
-    if (ticket == nwaves - 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (uint32_t k = lane; k < P; k += 64) {
-            a.hits[k] = __hip_atomic_exchange(a.scratch + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ unsigned long long s_ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's adds have been performed
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_ticket = __hip_atomic_fetch_add(a.scratch + kScratchDone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket == (unsigned long long)gridDim.x - 1 && threadIdx.x < 64) {
+        const uint32_t nslots = gridDim.x < (unsigned)kHitSlots ? gridDim.x : (unsigned)kHitSlots;
+        for (uint32_t k = 0; k < P; k++) {
+            unsigned long long v = 0;
+            if ((uint32_t)lane < nslots)
+                v = __hip_atomic_exchange(a.scratch + lane * kMaxKeys + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) a.hits[k] = v;
         }
         if (lane == 0) __hip_atomic_store(a.scratch + kScratchDone, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -317,10 +412,48 @@ __device__ __forceinline__ void hits_finalize(const ScanArgs &a, uint32_t P, int
 // on a store younger than the data it needs, whatever the number of stores per tile is; the DMA of
 // tile t+1 is in flight during the whole compute phase of tile t.
 //
-// MODE kModeEq / kModeRange: one bitmap.  MODE kModeShared: 8 keys per pass over the lane's registers
-// (one decode, 8 compares per value), ceil(P/8) passes per tile; the column is read from HBM once.
-// ABL (ablation, tools/tune_scan.hip only): 1 = DMA only, 2 = DMA + LDS reads, 3 = no bitmap stores.
-// AUX: bits 0-3 = cache policy of the DMA loads (0 default, 2 nt); bit 4 = non-temporal bitmap stores.
+// MODE kModeEq / kModeRange: one bitmap.  MODE kModeShared: up to 8 keys, one bitmap per key at
+// out + k*out_stride (one decode, 8 compares per value); the column is read from HBM once.  Larger P and
+// the linear layout go through shared_general_kernel below.
+// AUX_: bits 0-3 = cache policy of the DMA loads (0 default, 2 nt); bit 4 = non-temporal bitmap stores.
+// ABL (ablation / diagnostics, tools/tune_scan.hip only): 1 = DMA only, 2 = DMA + LDS reads, 3 = no bitmap
+// stores, 4 = normal + clock / placement stamps.
+template <int C, int VPL> struct TileCtx {
+    using G = ScanGeom<C, VPL>;
+    uint64_t n, ntiles, nfull, data_bytes;
+    __device__ __forceinline__ TileCtx(uint64_t n_) : n(n_)
+    {
+        ntiles = (n + G::TILE_VALUES - 1) / G::TILE_VALUES;
+        nfull = n / G::TILE_VALUES;
+        data_bytes = (n * C + 7) / 8;
+    }
+    template <int AUX> __device__ __forceinline__ void issue(const uint8_t *packed, uint64_t t, uint8_t *lds_wave, int lane) const
+    {
+        const uint8_t *src = packed + t * G::TILE_BYTES;
+        if (t < nfull)
+            dma_tile_full<G::TILE_BYTES, AUX>(src, lds_wave, lane);
+        else
+            dma_tile_partial<G::TILE_BYTES, AUX>(src, data_bytes - t * G::TILE_BYTES, lds_wave, lane);
+    }
+    // tail tile: zero bits >= n, write exactly ceil(n/8) bytes of the tile's bitmap; returns the lane's hit count
+    __device__ __forceinline__ uint32_t finish_tail(uint64_t t, uint32_t (&v)[VPL / 32], uint8_t *dst, uint64_t byte_stride, int lane) const
+    {
+        const int64_t left = (int64_t)(n - t * G::TILE_VALUES) - (int64_t)lane * VPL;
+        const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
+        const int nbytes = (valid + 7) / 8;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < VPL / 32; j++) {
+            v[j] &= tail_mask(valid, j);
+            cnt += __builtin_popcount(v[j]);
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (4 * j + b < nbytes) dst[(uint64_t)(4 * j + b) * byte_stride] = (uint8_t)(v[j] >> (8 * b));
+        }
+        return cnt;
+    }
+};
+
 template <int C, int MODE, int AUX_, int VPL, int ABL = 0>
 __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void scan_kernel(ScanArgs a)
 {
@@ -334,160 +467,178 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void sca
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint8_t *lds_wave = lds[wave];
-
-    const uint64_t n = a.n;
-    const uint64_t ntiles = (n + G::TILE_VALUES - 1) / G::TILE_VALUES;
-    const uint64_t nfull = n / G::TILE_VALUES;
-    const uint64_t data_bytes = (n * C + 7) / 8;
+    const TileCtx<C, VPL> tc(a.n);
     const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
     uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
-
-    auto issue = [&](uint64_t t) {
-        const uint8_t *src = a.packed + t * G::TILE_BYTES;
-        if (t < nfull)
-            dma_tile_full<G::TILE_BYTES, AUX>(src, lds_wave, lane);
-        else
-            dma_tile_partial<G::TILE_BYTES, AUX>(src, data_bytes - t * G::TILE_BYTES, lds_wave, lane);
-    };
-    // tail tile: zero bits >= n, write exactly ceil(n/8) bytes of the tile's bitmap
-    auto finish_tail = [&](uint64_t t, uint32_t (&v)[WORDS], uint8_t *dst, uint64_t byte_stride) -> uint32_t {
-        const int64_t left = (int64_t)(n - t * G::TILE_VALUES) - (int64_t)lane * VPL;
-        const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
-        const int nbytes = (valid + 7) / 8;
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int j = 0; j < WORDS; j++) {
-            v[j] &= tail_mask(valid, j);
-            cnt += __builtin_popcount(v[j]);
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-                if (4 * j + b < nbytes) dst[(uint64_t)(4 * j + b) * byte_stride] = (uint8_t)(v[j] >> (8 * b));
-        }
-        return cnt;
-    };
-
     const uint32_t P = (MODE == kModeShared) ? a.nkeys : 1;
-    const bool one_pass = P <= (uint32_t)kMaxKeysPerPass;
 
-    if (MODE != kModeShared || (one_pass && a.layout == 0)) {
-        // ---------------- pipelined loop: one pass of NK keys, per-predicate bitmaps ----------------
-        uint32_t key[kMaxKeysPerPass];
-#pragma unroll
-        for (int q = 0; q < kMaxKeysPerPass; q++) key[q] = a.key[q];
-        uint32_t hits[NK];
-#pragma unroll
-        for (int q = 0; q < NK; q++) hits[q] = 0;
+    unsigned long long stamp_c0 = 0, stamp_r0 = 0;
+    if constexpr (ABL == 4) { // diagnostic build: shader clock = d(memtime)/d(memrealtime) x 100 MHz
+        stamp_c0 = __builtin_amdgcn_s_memtime();
+        stamp_r0 = __builtin_amdgcn_s_memrealtime();
+    }
 
-        uint32_t res[NK][WORDS];
-        uint64_t prev = ~0ull; // tile whose results sit in `res`, not yet stored
-        if (tile < ntiles) issue(tile);
-        while (tile < ntiles) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            uint32_t w[G::LANE_DWORDS];
-            if constexpr (ABL != 1) read_lane_data<C, VPL>(lds_wave, lane, w);
-            // the LDS tile must be fully read before the next DMA may overwrite it
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (prev != ~0ull) { // every tile but a wave's last is a full tile
-                if constexpr (ABL == 0) {
+    uint32_t key[kMaxKeysPerPass];
 #pragma unroll
-                    for (int q = 0; q < NK; q++)
-                        if ((uint32_t)q < P)
-                            store_words<WORDS, NTS>(a.out + (uint64_t)q * a.out_stride + prev * G::BITMAP_BYTES + lane * (WORDS * 4), res[q]);
-                }
-            }
-            const uint64_t next = tile + stride;
-            if (next < ntiles) issue(next);
+    for (int q = 0; q < kMaxKeysPerPass; q++) key[q] = a.key[q];
+    uint32_t hits[NK];
+#pragma unroll
+    for (int q = 0; q < NK; q++) hits[q] = 0;
 
-            if constexpr (ABL == 1) {
-#pragma unroll
-                for (int q = 0; q < NK; q++)
-#pragma unroll
-                    for (int j = 0; j < WORDS; j++) res[q][j] = 0;
-            } else if constexpr (ABL == 2) {
-                uint32_t x = 0;
-#pragma unroll
-                for (int i = 0; i < G::LANE_DWORDS; i++) x ^= w[i];
-#pragma unroll
-                for (int q = 0; q < NK; q++)
-#pragma unroll
-                    for (int j = 0; j < WORDS; j++) res[q][j] = x;
-            } else {
-                decode_words<C, VPL, 0, NK, MODE, G::LANE_DWORDS>(w, res, key);
-            }
-            if (tile < nfull) {
-#pragma unroll
-                for (int q = 0; q < NK; q++)
-#pragma unroll
-                    for (int j = 0; j < WORDS; j++) hits[q] += __builtin_popcount(res[q][j]);
-                prev = tile;
-            } else {
-#pragma unroll
-                for (int q = 0; q < NK; q++)
-                    if ((uint32_t)q < P)
-                        hits[q] += finish_tail(tile, res[q], a.out + (uint64_t)q * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4), 1);
-                prev = ~0ull;
-            }
-            tile = next;
-        }
-        if (prev != ~0ull) {
-            if constexpr (ABL == 0) {
-#pragma unroll
-                for (int q = 0; q < NK; q++)
-                    if ((uint32_t)q < P)
-                        store_words<WORDS, NTS>(a.out + (uint64_t)q * a.out_stride + prev * G::BITMAP_BYTES + lane * (WORDS * 4), res[q]);
-            } else if (res[0][0] == 0x12345678u) { // keep the ablated pipeline alive
-                a.out[lane] = 1;
-            }
-        }
-        if (a.hits) {
-#pragma unroll
-            for (int q = 0; q < NK; q++) {
-                uint32_t s = wave_sum(hits[q]);
-                if ((uint32_t)q < P) hits_add(a, q, s, lane);
-            }
-        }
-        hits_finalize(a, P, lane);
-    } else if constexpr (MODE == kModeShared) {
-        // ---------------- general shared scan: any P (multi-pass), either layout ----------------
-        const uint32_t npass = (P + kMaxKeysPerPass - 1) / kMaxKeysPerPass;
-        if (tile < ntiles) issue(tile);
-        while (tile < ntiles) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            uint32_t w[G::LANE_DWORDS];
-            read_lane_data<C, VPL>(lds_wave, lane, w);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const uint64_t next = tile + stride;
-            if (next < ntiles) issue(next);
-            const bool full = tile < nfull;
+    // lane's byte offset inside a tile's bitmap, and the per-key bitmap bases
+    uint8_t *const out_lane = a.out + lane * (WORDS * 4);
+    const uint64_t kstride = a.out_stride;
 
-            for (uint32_t pass = 0; pass < npass; pass++) {
-                uint32_t key[kMaxKeysPerPass];
-                if (one_pass) {
-#pragma unroll
-                    for (int q = 0; q < kMaxKeysPerPass; q++) key[q] = a.key[q];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < kMaxKeysPerPass; q++)
-                        key[q] = __builtin_amdgcn_readfirstlane((uint32_t)a.keys_dev[pass * kMaxKeysPerPass + q]);
-                }
-                uint32_t res[NK][WORDS];
-                decode_words<C, VPL, 0, NK, MODE, G::LANE_DWORDS>(w, res, key);
+    uint32_t res[NK][WORDS];
+    uint64_t prev = ~0ull; // tile whose results sit in `res`, not yet stored
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+    while (tile < tc.ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t w[G::LANE_DWORDS];
+        if constexpr (ABL != 1) read_lane_data<C, VPL>(lds_wave, lane, w);
+        // the LDS tile must be fully read before the next DMA may overwrite it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (prev != ~0ull) { // every tile but a wave's last is a full tile
+            if constexpr (ABL == 0 || ABL == 4) {
+                uint8_t *dst = out_lane + prev * G::BITMAP_BYTES;
 #pragma unroll
                 for (int q = 0; q < NK; q++) {
-                    const uint32_t k = pass * kMaxKeysPerPass + q;
-                    if (k < P) {
+                    if ((uint32_t)q < P) store_words<WORDS, NTS>(dst, res[q]);
+                    dst += kstride;
+                }
+            }
+        }
+        const uint64_t next = tile + stride;
+        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+
+        if constexpr (ABL == 1) {
+#pragma unroll
+            for (int q = 0; q < NK; q++)
+#pragma unroll
+                for (int j = 0; j < WORDS; j++) res[q][j] = 0;
+        } else if constexpr (ABL == 2) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int i = 0; i < G::LANE_DWORDS; i++) x ^= w[i];
+#pragma unroll
+            for (int q = 0; q < NK; q++)
+#pragma unroll
+                for (int j = 0; j < WORDS; j++) res[q][j] = x;
+        } else {
+            decode_words<C, VPL, 0, NK, MODE, G::LANE_DWORDS>(w, res, key);
+        }
+        if (tile < tc.nfull) {
+#pragma unroll
+            for (int q = 0; q < NK; q++)
+#pragma unroll
+                for (int j = 0; j < WORDS; j++) hits[q] += __builtin_popcount(res[q][j]);
+            prev = tile;
+        } else {
+            uint8_t *dst = out_lane + tile * G::BITMAP_BYTES;
+#pragma unroll
+            for (int q = 0; q < NK; q++) {
+                if ((uint32_t)q < P) hits[q] += tc.finish_tail(tile, res[q], dst, 1, lane);
+                dst += kstride;
+            }
+            prev = ~0ull;
+        }
+        tile = next;
+    }
+    if (prev != ~0ull) {
+        if constexpr (ABL == 0 || ABL == 4) {
+            uint8_t *dst = out_lane + prev * G::BITMAP_BYTES;
+#pragma unroll
+            for (int q = 0; q < NK; q++) {
+                if ((uint32_t)q < P) store_words<WORDS, NTS>(dst, res[q]);
+                dst += kstride;
+            }
+        } else if (res[0][0] == 0x12345678u) { // keep the ablated pipeline alive
+            a.out[lane] = 1;
+        }
+    }
+    if (a.hits) {
+#pragma unroll
+        for (int q = 0; q < NK; q++) {
+            uint32_t s = wave_sum(hits[q]);
+            if ((uint32_t)q < P) hits_add(a, q, s, lane);
+        }
+    }
+    hits_finalize(a, P, lane);
+
+    if constexpr (ABL == 4) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.scratch[kScratchDone + 2] = __builtin_amdgcn_s_memtime() - stamp_c0;
+            a.scratch[kScratchDone + 3] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        }
+        if (threadIdx.x == 0 && a.keys_dev) { // per-block record: start, end (100 MHz ticks), HW_ID, XCC_ID
+            unsigned long long *dbg = (unsigned long long *)a.keys_dev + (uint64_t)blockIdx.x * 4;
+            dbg[0] = stamp_r0;
+            dbg[1] = __builtin_amdgcn_s_memrealtime();
+            dbg[2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+            dbg[3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
+        }
+    }
+}
+
+// ---- general shared scan: any P <= 1024 (ceil(P/8) passes of 8 keys over the lane's registers per tile),
+// per-predicate or linear output (byte of 8-value group g and key k at g*P + k,
+// src/simd_scan_shared_linear.cpp:57).  The tile's DMA is prefetched as above; results are stored pass by pass.
+template <int C, int AUX_, int VPL>
+__global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, kModeShared>())) void shared_general_kernel(ScanArgs a)
+{
+    using G = ScanGeom<C, VPL>;
+    constexpr int NK = kMaxKeysPerPass;
+    constexpr int WORDS = G::WORDS;
+    constexpr int AUX = AUX_ & 15;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t P = a.nkeys;
+    const bool keys_in_args = P <= (uint32_t)kMaxKeysPerPass;
+    const uint32_t npass = (P + kMaxKeysPerPass - 1) / kMaxKeysPerPass;
+
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+    while (tile < tc.ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t w[G::LANE_DWORDS];
+        read_lane_data<C, VPL>(lds_wave, lane, w);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint64_t next = tile + stride;
+        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        const bool full = tile < tc.nfull;
+
+        for (uint32_t pass = 0; pass < npass; pass++) {
+            uint32_t key[kMaxKeysPerPass];
+            if (keys_in_args) {
+#pragma unroll
+                for (int q = 0; q < kMaxKeysPerPass; q++) key[q] = a.key[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < kMaxKeysPerPass; q++)
+                    key[q] = __builtin_amdgcn_readfirstlane((uint32_t)a.keys_dev[pass * kMaxKeysPerPass + q]);
+            }
+            uint32_t res[NK][WORDS];
+            decode_words<C, VPL, 0, NK, kModeShared, G::LANE_DWORDS>(w, res, key);
+#pragma unroll
+            for (int q = 0; q < NK; q++) {
+                const uint32_t k = pass * kMaxKeysPerPass + q;
+                if (k < P) {
                     uint32_t cnt = 0;
                     if (a.layout == 0) {
                         uint8_t *dst = a.out + (uint64_t)k * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4);
                         if (full) {
 #pragma unroll
                             for (int j = 0; j < WORDS; j++) cnt += __builtin_popcount(res[q][j]);
-                            store_words<WORDS, NTS>(dst, res[q]);
+                            store_words<WORDS>(dst, res[q]);
                         } else {
-                            cnt = finish_tail(tile, res[q], dst, 1);
+                            cnt = tc.finish_tail(tile, res[q], dst, 1, lane);
                         }
                     } else {
-                        // linear: byte of 8-value group g and key k at g*P + k (src/simd_scan_shared_linear.cpp:57)
                         uint8_t *dst = a.out + (tile * G::BITMAP_BYTES + (uint64_t)lane * (WORDS * 4)) * P + k;
                         if (full) {
 #pragma unroll
@@ -497,17 +648,317 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void sca
                                 for (int b = 0; b < 4; b++) dst[(uint64_t)(4 * j + b) * P] = (uint8_t)(res[q][j] >> (8 * b));
                             }
                         } else {
-                            cnt = finish_tail(tile, res[q], dst, P);
+                            cnt = tc.finish_tail(tile, res[q], dst, P, lane);
                         }
                     }
                     if (a.hits) hits_add(a, k, wave_sum(cnt), lane);
+                }
+            }
+        }
+        tile = next;
+    }
+    hits_finalize(a, P, lane);
+}
+
+// ---- shared scan through an LDS lookup table ------------------------------------------------------
+// v_cmp / v_addc_co run at HALF rate on gfx950 (4.1 cycles per wave-instruction per SIMD against 2.3 for a plain
+// VOP2 op; tools/ubench_valu.hip), so the compare chain above costs 8 keys x 2 x 4.1 = 66 cycles per value and
+// is VALU-bound at ~1.5e12 values/s whatever the occupancy.  For P predicates the LUT form does ONE LDS byte
+// lookup per value and pass of 8 keys instead: entry[v] has bit q set iff v == key[q].  Eight consecutive
+// values give eight bytes = an 8x8 bit matrix (value x key); an in-register 8x8 bit transpose (3 masked
+// shift/xor rounds on a dword pair) turns it into the eight bitmap bytes (key x value).  That is ~1.1
+// cycles per (value, key) result instead of 8.2.
+//   C <= 10 : one table of 2^C entries per pass.
+//   C  > 10 : ceil(C/8) digit tables of 256 entries; entry_d[digit_d(v)] has bit q set iff digit_d(key[q]) ==
+//             digit_d(v); the AND over the digits is exact equality.
+// Keys outside [0, 2^C) get no bit anywhere (they match nothing, as in the reference).  P <= 64 (8 passes).
+constexpr int kLutMaxPasses = 8;
+
+template <int C> struct LutGeom {
+    static constexpr bool SINGLE = C <= 10;
+    static constexpr int ND = SINGLE ? 1 : (C + 7) / 8;
+    static constexpr int ENTRIES = SINGLE ? (1 << C) : 256;
+    static constexpr int TABLE_BYTES = ND * ENTRIES; // per pass of 8 keys
+};
+
+// 8x8 bit transpose of the 64-bit matrix (hi:lo): bit (8r + c) <-> bit (8c + r)
+__device__ __forceinline__ void transpose8x8(uint32_t &lo, uint32_t &hi)
+{
+    uint32_t t;
+    t = (lo ^ (lo >> 7)) & 0x00AA00AAu;  lo ^= t ^ (t << 7);
+    t = (hi ^ (hi >> 7)) & 0x00AA00AAu;  hi ^= t ^ (t << 7);
+    t = (lo ^ (lo >> 14)) & 0x0000CCCCu; lo ^= t ^ (t << 14);
+    t = (hi ^ (hi >> 14)) & 0x0000CCCCu; hi ^= t ^ (t << 14);
+    // 64-bit round: t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0 ; x ^= t ^ (t << 28)
+    t = (lo ^ ((lo >> 28) | (hi << 4))) & 0xF0F0F0F0u;
+    lo ^= t;
+    hi ^= t >> 4;
+}
+
+// 4x4 byte transpose: c[j] byte i = r[i] byte j   (v_perm_b32: selector 0-3 = bytes of the 2nd operand, 4-7 = 1st)
+__device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&r)[4], uint32_t (&c)[4])
+{
+    const uint32_t t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u); // r0.b0 r1.b0 r0.b1 r1.b1
+    const uint32_t t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u); // r0.b2 r1.b2 r0.b3 r1.b3
+    const uint32_t t2 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u);
+    const uint32_t t3 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+    c[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); // t0.b0 t0.b1 t2.b0 t2.b1
+    c[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u); // t0.b2 t0.b3 t2.b2 t2.b3
+    c[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    c[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+
+template <int C, int I> __device__ __forceinline__ uint32_t lut_lookup(const uint8_t *table, uint32_t x)
+{
+    using L = LutGeom<C>;
+    if constexpr (L::SINGLE) {
+        return table[x];
+    } else {
+        uint32_t m = table[x & 255u];
+#pragma unroll
+        for (int d = 1; d < L::ND; d++) {
+            const uint32_t digit = (d == L::ND - 1) ? (x >> (8 * d)) : ((x >> (8 * d)) & 255u);
+            m &= table[d * 256 + digit];
+        }
+        return m;
+    }
+}
+
+// Y[g] = (lo, hi): byte q of the pair = bitmap byte of key q for the lane's 8-value group g
+template <int C, int VPL, int G, bool TAIL, int NW>
+__device__ __forceinline__ void lut_groups(const uint32_t (&w)[NW], const uint8_t *table, int valid, uint32_t (&Y)[VPL / 8][2])
+{
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t x;
+        // compile-time position: one template instantiation per value
+        if constexpr (true) {
+            constexpr int K = 8 * G;
+            switch (i) { // unrolled: i is a constant after unrolling
+            case 0: x = extract<C, K + 0, NW>(w); break;
+            case 1: x = extract<C, K + 1, NW>(w); break;
+            case 2: x = extract<C, K + 2, NW>(w); break;
+            case 3: x = extract<C, K + 3, NW>(w); break;
+            case 4: x = extract<C, K + 4, NW>(w); break;
+            case 5: x = extract<C, K + 5, NW>(w); break;
+            case 6: x = extract<C, K + 6, NW>(w); break;
+            default: x = extract<C, K + 7, NW>(w); break;
+            }
+        }
+        uint32_t m = lut_lookup<C, 0>(table, x);
+        if constexpr (TAIL) m = (8 * G + i < valid) ? m : 0u;
+        if (i < 4)
+            lo |= m << (8 * i);
+        else
+            hi |= m << (8 * (i - 4));
+    }
+    transpose8x8(lo, hi);
+    Y[G][0] = lo;
+    Y[G][1] = hi;
+    if constexpr (G + 1 < VPL / 8) lut_groups<C, VPL, G + 1, TAIL, NW>(w, table, valid, Y);
+}
+
+// per-key bitmap words of the lane: out[q][j] = bytes q of Y[4j..4j+3]
+template <int VPL> __device__ __forceinline__ void lut_gather_keys(const uint32_t (&Y)[VPL / 8][2], uint32_t (&out)[8][VPL / 32])
+{
+#pragma unroll
+    for (int j = 0; j < VPL / 32; j++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t r[4] = {Y[4 * j + 0][h], Y[4 * j + 1][h], Y[4 * j + 2][h], Y[4 * j + 3][h]};
+            uint32_t c[4];
+            transpose4x4_bytes(r, c);
+#pragma unroll
+            for (int q = 0; q < 4; q++) out[4 * h + q][j] = c[q];
+        }
+    }
+}
+
+// LAYOUT 0: per-predicate bitmaps at out + k*out_stride; 1: linear (byte of 8-value group g and key k at
+// g*P + k, src/simd_scan_shared_linear.cpp:57).  MULTI false: P <= 8, one pass, stores deferred by one tile
+// (as in scan_kernel); true: ceil(P/8) passes per tile, stored pass by pass.
+template <int C, int AUX_, int VPL, int LAYOUT, bool MULTI>
+__global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
+{
+    using G = ScanGeom<C, VPL>;
+    using L = LutGeom<C>;
+    constexpr int WORDS = G::WORDS;
+    constexpr int GROUPS = VPL / 8;
+    constexpr int AUX = AUX_ & 15;
+    constexpr int NRES = LAYOUT == 0 ? 8 * WORDS : GROUPS * 2; // result dwords per lane, tile and pass
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[(MULTI ? kLutMaxPasses : 1) * L::TABLE_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t P = a.nkeys;
+    const uint32_t npass = MULTI ? (P + 7) / 8 : 1;
+
+    // the tile's DMA does not depend on the tables: get it going first
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+
+    for (uint32_t i = threadIdx.x; i < npass * L::TABLE_BYTES; i += kBlockThreads) {
+        const uint32_t pass = i / L::TABLE_BYTES, r = i % L::TABLE_BYTES;
+        const uint32_t digit = r / L::ENTRIES, e = r % L::ENTRIES;
+        uint32_t byte = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t k = pass * 8 + q;
+            if (k < P) {
+                const uint32_t key = MULTI ? (uint32_t)a.keys_dev[k] : a.key[q];
+                const bool in_range = C == 32 || (key >> (C & 31)) == 0;
+                const uint32_t d = L::SINGLE ? key : ((key >> (8 * digit)) & 255u);
+                if (in_range && d == e) byte |= 1u << q;
+            }
+        }
+        lut[i] = (uint8_t)byte;
+    }
+    __syncthreads();
+
+    uint32_t hits[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) hits[q] = 0;
+
+    // full-tile store of one pass: LAYOUT 0: res = out[q][j] (q-major); LAYOUT 1: res = Y[g][0..1]
+    auto store_full = [&](uint64_t t, uint32_t pass, const uint32_t (&res)[NRES]) {
+        if constexpr (LAYOUT == 0) {
+            uint8_t *dst = a.out + (uint64_t)(pass * 8) * a.out_stride + t * G::BITMAP_BYTES + lane * (WORDS * 4);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (pass * 8 + q < P) {
+                    uint32_t v[WORDS];
+#pragma unroll
+                    for (int j = 0; j < WORDS; j++) v[j] = res[q * WORDS + j];
+                    store_words<WORDS>(dst, v);
+                }
+                dst += a.out_stride;
+            }
+        } else {
+            const uint64_t g0 = t * G::BITMAP_BYTES + (uint64_t)lane * GROUPS;
+            if (!MULTI && P == 8) { // the lane's GROUPS x 8 keys are 8*GROUPS contiguous bytes
+                u32x4 *dst = (u32x4 *)(a.out + g0 * 8);
+#pragma unroll
+                for (int g = 0; g < GROUPS; g += 2) {
+                    u32x4 v = {res[2 * g], res[2 * g + 1], res[2 * g + 2], res[2 * g + 3]};
+                    dst[g / 2] = v;
+                }
+            } else {
+                const uint32_t nk = (P - pass * 8) < 8 ? (P - pass * 8) : 8;
+                const bool whole = nk == 8 && (P & 7) == 0;
+#pragma unroll
+                for (int g = 0; g < GROUPS; g++) {
+                    uint8_t *dst = a.out + (g0 + g) * P + pass * 8;
+                    if (whole) {
+                        u32x2 v = {res[2 * g], res[2 * g + 1]};
+                        *(u32x2 *)dst = v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; q++)
+                            if ((uint32_t)q < nk) dst[q] = (uint8_t)(res[2 * g + (q >> 2)] >> (8 * (q & 3)));
                     }
                 }
             }
-            tile = next;
         }
-        hits_finalize(a, P, lane);
+    };
+
+    uint32_t resp[NRES]; // !MULTI: results of the previous tile, not yet stored
+    uint64_t prev = ~0ull;
+
+    while (tile < tc.ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t w[G::LANE_DWORDS];
+        read_lane_data<C, VPL>(lds_wave, lane, w);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!MULTI) {
+            if (prev != ~0ull) store_full(prev, 0, resp);
+            prev = ~0ull;
+        }
+        const uint64_t next = tile + stride;
+        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        const bool full = tile < tc.nfull;
+
+        for (uint32_t pass = 0; pass < npass; pass++) {
+            const uint8_t *table = lut + pass * L::TABLE_BYTES;
+            uint32_t Y[GROUPS][2];
+            uint32_t out[8][WORDS];
+            if (full) {
+                lut_groups<C, VPL, 0, false, G::LANE_DWORDS>(w, table, VPL, Y);
+                lut_gather_keys<VPL>(Y, out);
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+#pragma unroll
+                    for (int j = 0; j < WORDS; j++) hits[q] += __builtin_popcount(out[q][j]);
+                uint32_t res[NRES];
+                if constexpr (LAYOUT == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+#pragma unroll
+                        for (int j = 0; j < WORDS; j++) res[q * WORDS + j] = out[q][j];
+                } else {
+#pragma unroll
+                    for (int g = 0; g < GROUPS; g++) { res[2 * g] = Y[g][0]; res[2 * g + 1] = Y[g][1]; }
+                }
+                if constexpr (!MULTI) {
+#pragma unroll
+                    for (int i = 0; i < NRES; i++) resp[i] = res[i];
+                    prev = tile;
+                } else {
+                    if (a.hits) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            if (pass * 8 + q < P) hits_add(a, pass * 8 + q, wave_sum(hits[q]), lane);
+                            hits[q] = 0;
+                        }
+                    }
+                    store_full(tile, pass, res);
+                }
+            } else {
+                // tail tile: lookups of values >= n are zeroed; the bitmap is written byte-exact
+                const int64_t left = (int64_t)(tc.n - tile * G::TILE_VALUES) - (int64_t)lane * VPL;
+                const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
+                const int nbytes = (valid + 7) / 8;
+                lut_groups<C, VPL, 0, true, G::LANE_DWORDS>(w, table, valid, Y);
+                lut_gather_keys<VPL>(Y, out);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t k = pass * 8 + q;
+                    if (k < P) {
+                        uint32_t cnt = 0;
+#pragma unroll
+                        for (int j = 0; j < WORDS; j++) cnt += __builtin_popcount(out[q][j]);
+                        if constexpr (!MULTI)
+                            hits[q] += cnt;
+                        else if (a.hits)
+                            hits_add(a, k, wave_sum(cnt), lane);
+                        uint8_t *dst = LAYOUT == 0
+                                           ? a.out + (uint64_t)k * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4)
+                                           : a.out + (tile * G::BITMAP_BYTES + (uint64_t)lane * GROUPS) * P + k;
+                        const uint64_t bstride = LAYOUT == 0 ? 1 : P;
+#pragma unroll
+                        for (int b = 0; b < WORDS * 4; b++)
+                            if (b < nbytes) dst[(uint64_t)b * bstride] = (uint8_t)(out[q][b >> 2] >> (8 * (b & 3)));
+                    }
+                }
+            }
+        }
+        tile = next;
     }
+    if constexpr (!MULTI) {
+        if (prev != ~0ull) store_full(prev, 0, resp);
+        if (a.hits) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                uint32_t s = wave_sum(hits[q]);
+                if ((uint32_t)q < P) hits_add(a, q, s, lane);
+            }
+        }
+    }
+    hits_finalize(a, P, lane);
 }
 
 // ---- decompression to int32 -------------------------------------------------------------------

@@ -54,7 +54,45 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
     switch (r.op) {
     case kOpScanEq: launch_scan<C, kModeEq>(r); break;
     case kOpScanRange: launch_scan<C, kModeRange>(r); break;
-    case kOpSharedScan: launch_scan<C, kModeShared>(r); break;
+    case kOpSharedScan: {
+        constexpr int VPL = scan_vpl(C, kModeShared);
+        using G = ScanGeom<C, VPL>;
+        const uint64_t ntiles = (r.scan.n + G::TILE_VALUES - 1) / G::TILE_VALUES;
+        const uint32_t P = r.scan.nkeys;
+        const bool linear = r.scan.layout != 0;
+        // measured (tools/tune_scan.hip, 1e9 x 9 bit, P = 8): one block per CU 0.41 ms, two 0.46, three 0.49
+        // (tools/sweep.py: c = 5, 2.5 KiB tiles, is the exception -- two blocks 0.30 ms against 0.37)
+        auto lut_bpc = [&](int occ) {
+            const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : (G::TILE_BYTES < 4096 ? 2 : 1);
+            return want < occ ? want : occ;
+        };
+        if (P <= 8) { // LDS lookup table, one pass, deferred stores
+            if (linear) {
+                static const int bpc = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 1, false>);
+                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, false>), dim3(grid_for(ntiles, lut_bpc(bpc), r.num_cus)),
+                                   dim3(kBlockThreads), 0, r.stream, r.scan);
+            } else {
+                static const int bpc = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 0, false>);
+                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, false>), dim3(grid_for(ntiles, lut_bpc(bpc), r.num_cus)),
+                                   dim3(kBlockThreads), 0, r.stream, r.scan);
+            }
+        } else if (P <= 8 * (uint32_t)kLutMaxPasses) { // lookup tables for up to 64 keys, pass by pass
+            if (linear) {
+                static const int bpc = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 1, true>);
+                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, true>), dim3(grid_for(ntiles, lut_bpc(bpc), r.num_cus)),
+                                   dim3(kBlockThreads), 0, r.stream, r.scan);
+            } else {
+                static const int bpc = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 0, true>);
+                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, true>), dim3(grid_for(ntiles, lut_bpc(bpc), r.num_cus)),
+                                   dim3(kBlockThreads), 0, r.stream, r.scan);
+            }
+        } else { // more keys than the tables hold: compare chain, ceil(P/8) passes over the registers
+            static const int bpc = blocks_per_cu(shared_general_kernel<C, 2, VPL>);
+            hipLaunchKernelGGL((shared_general_kernel<C, 2, VPL>), dim3(grid_for(ntiles, cap_bpc(bpc, r), r.num_cus)), dim3(kBlockThreads), 0,
+                               r.stream, r.scan);
+        }
+        break;
+    }
     case kOpDecompress: {
         static const int bpc = blocks_per_cu(decompress_kernel<C, 2>);
         const uint64_t ntiles = (r.decomp.n + DecompGeom<C>::TILE_VALUES - 1) / DecompGeom<C>::TILE_VALUES;

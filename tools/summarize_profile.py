@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     src, workload, tag, rows, bits = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
     kmatch = {"scan_eq": "scan_kernel<%d, 0," % bits, "scan_range": "scan_kernel<%d, 1," % bits,
-              "shared_scan": "scan_kernel<%d, 2," % bits, "decompress": "decompress_kernel<%d," % bits}[workload]
+              "shared_scan": "shared_lut_kernel<%d," % bits, "decompress": "decompress_kernel<%d," % bits}[workload]
     stats = None
     for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):

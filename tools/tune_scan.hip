@@ -77,8 +77,8 @@ int main(int argc, char **argv)
     CK(hipMalloc(&bitmap, n / 8 + 4096));
     CK(hipMalloc(&hits, 64));
     unsigned long long *scratch;
-    CK(hipMalloc(&scratch, (kScratchDone + 8) * 8));
-    CK(hipMemset(scratch, 0, (kScratchDone + 8) * 8));
+    CK(hipMalloc(&scratch, kScratchWords * 8));
+    CK(hipMemset(scratch, 0, kScratchWords * 8));
     CK(hipMalloc(&sink, 64));
     PackArgs pa{};
     pa.n = n;
@@ -130,6 +130,57 @@ int main(int argc, char **argv)
     SCAN_VARIANT("vpl128 nt ABL3 no-store", 128, 2, 3, read_bytes);
     SCAN_VARIANT("vpl64 nt ABL1 dma-only", 64, 2, 1, read_bytes);
     SCAN_VARIANT("vpl64 nt ABL3 no-store", 64, 2, 3, read_bytes);
+    // shared scan, 8 keys, per-predicate bitmaps (needs 8 bitmaps: reuse one big buffer)
+    uint8_t *bitmap8;
+    const uint64_t stride8 = ((n / 8 + 4096 + 15) / 16) * 16;
+    CK(hipMalloc(&bitmap8, stride8 * 8));
+    unsigned long long *dbg;
+    CK(hipMalloc(&dbg, 8192 * 32));
+    CK(hipMemset(dbg, 0, 8192 * 32));
+    sa.keys_dev = (const int32_t *)dbg;
+    ScanArgs sh = sa;
+    sh.out = bitmap8;
+    sh.out_stride = stride8;
+    sh.nkeys = 8;
+    sh.layout = 0;
+    for (int q = 0; q < 8; q++) sh.key[q] = q;
+    const double shared_bytes = n * C / 8.0 + n;
+#define SHARED_VARIANT(NAME, VPL, ABL, BYTES)                                                                           \
+    vs.push_back({NAME,                                                                                                \
+                  [=](int bpc, hipStream_t s) {                                                                        \
+                      using G = ScanGeom<C, VPL>;                                                                      \
+                      uint64_t ntiles = (n + G::TILE_VALUES - 1) / G::TILE_VALUES;                                     \
+                      uint64_t want = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;                                  \
+                      unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)bpc * cus);                         \
+                      hipLaunchKernelGGL((scan_kernel<C, kModeShared, 2, VPL, ABL>), dim3(grid), dim3(kBlockThreads),  \
+                                         0, s, sh);                                                                    \
+                  },                                                                                                   \
+                  (scan_occ<C, VPL, kModeShared>()), BYTES, false})
+#define LUT_VARIANT(NAME, VPL, LAYOUT)                                                                                   \
+    vs.push_back({NAME,                                                                                                \
+                  [=](int bpc, hipStream_t s) {                                                                        \
+                      using G = ScanGeom<C, VPL>;                                                                      \
+                      uint64_t ntiles = (n + G::TILE_VALUES - 1) / G::TILE_VALUES;                                     \
+                      uint64_t want = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;                                  \
+                      unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)bpc * cus);                         \
+                      ScanArgs x = sh;                                                                                 \
+                      x.layout = LAYOUT;                                                                               \
+                      hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, LAYOUT, false>), dim3(grid),                    \
+                                         dim3(kBlockThreads), 0, s, x);                                                \
+                  },                                                                                                   \
+                  3, shared_bytes, false})
+    LUT_VARIANT("lut8 vpl64 per-pred", 64, 0);
+    LUT_VARIANT("lut8 vpl64 linear", 64, 1);
+    LUT_VARIANT("lut8 vpl128 per-pred", 128, 0);
+    SHARED_VARIANT("shared8 vpl64", 64, 0, shared_bytes);
+    SHARED_VARIANT("shared8 vpl64 ABL1 dma-only", 64, 1, read_bytes);
+    SHARED_VARIANT("shared8 vpl64 ABL2 dma+lds", 64, 2, read_bytes);
+    SHARED_VARIANT("shared8 vpl64 ABL3 no-store", 64, 3, read_bytes);
+    SHARED_VARIANT("shared8 vpl64 ABL4 stamps", 64, 4, shared_bytes);
+    SCAN_VARIANT("vpl128 nt ABL4 stamps", 128, 2, 4, scan_bytes);
+    SHARED_VARIANT("shared8 vpl128", 128, 0, shared_bytes);
+    SHARED_VARIANT("shared8 vpl32", 32, 0, shared_bytes);
+    SHARED_VARIANT("shared8 vpl32 ABL3 no-store", 32, 3, read_bytes);
     const uint64_t nvec = (n * C / 8) / 16;
     vs.push_back({"read x4 unroll4", [=](int bpc, hipStream_t s) {
                       hipLaunchKernelGGL((read_kernel<4, 0>), dim3(bpc * cus), dim3(256), 0, s, (const u32x4 *)packed, nvec, sink);
@@ -159,6 +210,33 @@ int main(int argc, char **argv)
         vs[c.v].launch(c.bpc, 0);
         CK(hipMemcpy(&c.hits, hits, 8, hipMemcpyDeviceToHost));
         CK(hipGetLastError());
+        if (vs[c.v].name.find("ABL4") != std::string::npos) {
+            unsigned long long st[2];
+            CK(hipMemcpy(st, scratch + kScratchDone + 2, 16, hipMemcpyDeviceToHost));
+            {
+                std::vector<unsigned long long> h(8192 * 4);
+                CK(hipMemcpy(h.data(), dbg, 8192 * 32, hipMemcpyDeviceToHost));
+                int nb = c.bpc * cus;
+                unsigned long long t0 = ~0ull, t1 = 0;
+                for (int b = 0; b < nb; b++) { t0 = std::min(t0, h[b * 4]); t1 = std::max(t1, h[b * 4 + 1]); }
+                // histogram of blocks per (xcc, se, sh, cu) and of start times
+                std::vector<int> percu(8 * 8 * 2 * 16, 0);
+                int late = 0;
+                double sumdur = 0;
+                for (int b = 0; b < nb; b++) {
+                    unsigned hw = (unsigned)h[b * 4 + 2], xcc = (unsigned)h[b * 4 + 3] & 15;
+                    unsigned cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+                    percu[((xcc * 8 + se) * 2 + sh) * 16 + cu]++;
+                    if (h[b * 4] - t0 > (t1 - t0) / 10) late++;
+                    sumdur += (double)(h[b * 4 + 1] - h[b * 4]);
+                }
+                int used = 0, mx = 0;
+                for (int v : percu) { used += v > 0; mx = std::max(mx, v); }
+                printf("[blocks] %-26s bpc=%d: %d blocks on %d distinct CUs (max %d per CU); %d started later than 10%% into the kernel; span %.1f us, mean block lifetime %.1f us\n",
+                       vs[c.v].name.c_str(), c.bpc, nb, used, mx, late, (t1 - t0) * 0.01, sumdur / nb * 0.01);
+            }
+            printf("[clock] %-28s bpc=%d: %llu shader cycles / %llu ticks of 100 MHz = %.3f GHz\n", vs[c.v].name.c_str(), c.bpc, st[0], st[1], st[0] / (double)st[1] * 0.1);
+        }
     }
     for (int r = 0; r < REPS; r++) {
         for (auto &c : cfgs) {
