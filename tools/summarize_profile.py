@@ -20,13 +20,18 @@ def main():
     kmatch = {"scan_eq": "scan_kernel<%d, 0," % bits, "scan_range": "scan_kernel<%d, 1," % bits,
               "shared_scan": "shared_lut_kernel<%d," % bits, "decompress": "decompress_kernel<%d," % bits}[workload]
     stats = None
-    for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+    newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1:]  # noqa: E731  (re-runs leave older files)
+    for f in newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
             if kmatch in r["Name"]:
                 stats = r
     counters = collections.defaultdict(list)
     meta = {}
-    for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+    pmc_files = []
+    for d in glob.glob(os.path.join(src, "pmc_*")):
+        if os.path.isdir(d):
+            pmc_files += newest(os.path.join(d, "*", "*_counter_collection.csv"))
+    for f in pmc_files:
         for r in csv.DictReader(open(f)):
             if kmatch in r["Kernel_Name"]:
                 counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
