@@ -68,8 +68,8 @@ MI355_API int mi355_ctx_create(int device, void *hip_stream /* hipStream_t or NU
 MI355_API int mi355_ctx_destroy(mi355_ctx *ctx);
 MI355_API int mi355_ctx_synchronize(mi355_ctx *ctx);
 MI355_API int mi355_device_count(int *count);
-/* tuning knobs: "max_blocks_per_cu" (0 = occupancy limit), "dma_aux" (cache policy of the HBM->LDS
- * loads of the equality scan: 0 default, 2 non-temporal) */
+/* tuning knobs: "max_blocks_per_cu" (0 = the engine's per-kernel default), "dma_aux" (bits 0-3: cache policy of
+ * the HBM->LDS loads, 0 default / 2 non-temporal; bit 4: non-temporal output stores in decompress; default 18) */
 MI355_API int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value);
 
 /* ---- buffer sizing, in bytes.  replaces: compressed_buffer_size / decompression_output_buffer_size

@@ -25,7 +25,8 @@ struct mi355_ctx {
     hipStream_t stream = nullptr;
     int num_cus = 256;
     int max_blocks_per_cu = 0;
-    int dma_aux = 2; // non-temporal HBM->LDS loads: the column is streamed once
+    int dma_aux = 18; // bits 0-3: policy of the HBM->LDS loads (2 = non-temporal: the column is streamed once);
+                      // bit 4: non-temporal stores in decompress
     unsigned long long *hits_scratch = nullptr; // host-pointer API: where the kernels deliver hit counts
     unsigned long long *kernel_scratch = nullptr; // kScratchWords words, all zero between launches (kernels.hpp hits_finalize)
     int32_t *keys_scratch = nullptr;            // 1024 + 8 keys

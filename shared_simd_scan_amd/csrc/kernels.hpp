@@ -981,10 +981,12 @@ struct DecompArgs {
     int32_t *out;
 };
 
-template <int C, int AUX>
+template <int C, int AUX_>
 __global__ __launch_bounds__(kBlockThreads) void decompress_kernel(DecompArgs a)
 {
     using G = DecompGeom<C>;
+    constexpr int AUX = AUX_ & 15;          // cache policy of the DMA loads
+    constexpr bool NTS = (AUX_ & 16) != 0;  // non-temporal stores of the int32 output
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1030,7 +1032,7 @@ __global__ __launch_bounds__(kBlockThreads) void decompress_kernel(DecompArgs a)
                     uint32_t hi = lds32[s * 8 * C + didx[j] + 1];
                     v[j] = __builtin_amdgcn_alignbit(hi, lo, sh[j]) & mask;
                 }
-                *(u32x4 *)(dst + s * 256) = v;
+                if constexpr (NTS) __builtin_nontemporal_store(v, (u32x4 *)(dst + s * 256)); else *(u32x4 *)(dst + s * 256) = v;
             }
         } else {
             const uint64_t base = tile * G::TILE_VALUES;

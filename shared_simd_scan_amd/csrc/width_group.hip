@@ -94,13 +94,15 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         break;
     }
     case kOpDecompress: {
-        static const int bpc = blocks_per_cu(decompress_kernel<C, 2>);
+        static const int bpc = blocks_per_cu(decompress_kernel<C, 18>);
         const uint64_t ntiles = (r.decomp.n + DecompGeom<C>::TILE_VALUES - 1) / DecompGeom<C>::TILE_VALUES;
         const unsigned grid = grid_for(ntiles, cap_bpc(bpc, r), r.num_cus);
         if (r.dma_aux == 0)
             hipLaunchKernelGGL((decompress_kernel<C, 0>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);
-        else
+        else if (r.dma_aux == 2) // nt DMA loads only (tools/sweep.py --aux 2)
             hipLaunchKernelGGL((decompress_kernel<C, 2>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);
+        else // default (dma_aux 18): nt loads + nt stores -- the 4 B/value output is written once (+1-2 %)
+            hipLaunchKernelGGL((decompress_kernel<C, 18>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);
         break;
     }
     default:
