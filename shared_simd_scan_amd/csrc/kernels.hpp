@@ -345,6 +345,16 @@ __device__ __forceinline__ uint32_t tail_mask(int valid, int J)
     return v >= 32 ? 0xffffffffu : (v <= 0 ? 0u : ((1u << v) - 1u));
 }
 
+// 8 bytes at an arbitrary byte address: one global_store_dwordx2 (gfx950 handles the misalignment in hardware)
+struct __attribute__((packed, aligned(1))) Unaligned64 { uint32_t lo, hi; };
+__device__ __forceinline__ void store8_unaligned(uint8_t *dst, uint32_t lo, uint32_t hi)
+{
+    Unaligned64 v;
+    v.lo = lo;
+    v.hi = hi;
+    *(Unaligned64 *)dst = v;
+}
+
 // NT: non-temporal store (the bitmap is written once and not re-read by this kernel)
 template <int WORDS, bool NT = false> __device__ __forceinline__ void store_words(uint8_t *dst, const uint32_t (&v)[WORDS])
 {
@@ -580,6 +590,19 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void sca
     }
 }
 
+// 4x4 byte transpose: c[j] byte i = r[i] byte j   (v_perm_b32: selector 0-3 = bytes of the 2nd operand, 4-7 = 1st)
+__device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&r)[4], uint32_t (&c)[4])
+{
+    const uint32_t t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u); // r0.b0 r1.b0 r0.b1 r1.b1
+    const uint32_t t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u); // r0.b2 r1.b2 r0.b3 r1.b3
+    const uint32_t t2 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u);
+    const uint32_t t3 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+    c[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); // t0.b0 t0.b1 t2.b0 t2.b1
+    c[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u); // t0.b2 t0.b3 t2.b2 t2.b3
+    c[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    c[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+
 // ---- general shared scan: any P <= 1024 (ceil(P/8) passes of 8 keys over the lane's registers per tile),
 // per-predicate or linear output (byte of 8-value group g and key k at g*P + k,
 // src/simd_scan_shared_linear.cpp:57).  The tile's DMA is prefetched as above; results are stored pass by pass.
@@ -638,20 +661,39 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, kModeShared>())) v
                         } else {
                             cnt = tc.finish_tail(tile, res[q], dst, 1, lane);
                         }
-                    } else {
+                    } else if (!full) {
                         uint8_t *dst = a.out + (tile * G::BITMAP_BYTES + (uint64_t)lane * (WORDS * 4)) * P + k;
-                        if (full) {
+                        cnt = tc.finish_tail(tile, res[q], dst, P, lane);
+                    } else {
 #pragma unroll
-                            for (int j = 0; j < WORDS; j++) {
-                                cnt += __builtin_popcount(res[q][j]);
-#pragma unroll
-                                for (int b = 0; b < 4; b++) dst[(uint64_t)(4 * j + b) * P] = (uint8_t)(res[q][j] >> (8 * b));
-                            }
-                        } else {
-                            cnt = tc.finish_tail(tile, res[q], dst, P, lane);
-                        }
+                        for (int j = 0; j < WORDS; j++) cnt += __builtin_popcount(res[q][j]);
                     }
                     if (a.hits) hits_add(a, k, wave_sum(cnt), lane);
+                }
+            }
+            if (a.layout != 0 && full) {
+                // linear: the 8 keys of this pass are 8 consecutive bytes of every 8-value group: gather them
+                // with 4x4 byte transposes (key-major words -> group-major key bytes) and store 8 bytes per group
+                const uint32_t nk = (P - pass * 8) < 8 ? (P - pass * 8) : 8;
+                const uint64_t g0 = tile * G::BITMAP_BYTES + (uint64_t)lane * (WORDS * 4);
+#pragma unroll
+                for (int j = 0; j < WORDS; j++) {
+                    const uint32_t r0[4] = {res[0][j], res[1][j], res[2][j], res[3][j]};
+                    const uint32_t r1[4] = {res[4][j], res[5][j], res[6][j], res[7][j]};
+                    uint32_t c0[4], c1[4]; // c0[b] = bytes of keys 0..3 for group 4j+b; c1[b] = keys 4..7
+                    transpose4x4_bytes(r0, c0);
+                    transpose4x4_bytes(r1, c1);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        uint8_t *dst = a.out + (g0 + 4 * j + b) * P + pass * 8;
+                        if (nk == 8) {
+                            store8_unaligned(dst, c0[b], c1[b]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 8; q++)
+                                if ((uint32_t)q < nk) dst[q] = (uint8_t)((q < 4 ? c0[b] : c1[b]) >> (8 * (q & 3)));
+                        }
+                    }
                 }
             }
         }
@@ -672,7 +714,9 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, kModeShared>())) v
 //   C  > 10 : ceil(C/8) digit tables of 256 entries; entry_d[digit_d(v)] has bit q set iff digit_d(key[q]) ==
 //             digit_d(v); the AND over the digits is exact equality.
 // Keys outside [0, 2^C) get no bit anywhere (they match nothing, as in the reference).  P <= 64 (8 passes).
-constexpr int kLutMaxPasses = 8;
+constexpr int kLutMaxPasses = kMaxKeys / 8; // as many as fit in LDS beside the tiles (checked by the launcher)
+
+extern __shared__ uint8_t mi355_dyn_lds[]; // lookup tables of the multi-pass LUT kernel (size set at launch)
 
 template <int C> struct LutGeom {
     static constexpr bool SINGLE = C <= 10;
@@ -693,19 +737,6 @@ __device__ __forceinline__ void transpose8x8(uint32_t &lo, uint32_t &hi)
     t = (lo ^ ((lo >> 28) | (hi << 4))) & 0xF0F0F0F0u;
     lo ^= t;
     hi ^= t >> 4;
-}
-
-// 4x4 byte transpose: c[j] byte i = r[i] byte j   (v_perm_b32: selector 0-3 = bytes of the 2nd operand, 4-7 = 1st)
-__device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&r)[4], uint32_t (&c)[4])
-{
-    const uint32_t t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u); // r0.b0 r1.b0 r0.b1 r1.b1
-    const uint32_t t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u); // r0.b2 r1.b2 r0.b3 r1.b3
-    const uint32_t t2 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u);
-    const uint32_t t3 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
-    c[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); // t0.b0 t0.b1 t2.b0 t2.b1
-    c[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u); // t0.b2 t0.b3 t2.b2 t2.b3
-    c[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
-    c[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
 }
 
 template <int C, int I> __device__ __forceinline__ uint32_t lut_lookup(const uint8_t *table, uint32_t x)
@@ -759,6 +790,34 @@ __device__ __forceinline__ void lut_groups(const uint32_t (&w)[NW], const uint8_
     if constexpr (G + 1 < VPL / 8) lut_groups<C, VPL, G + 1, TAIL, NW>(w, table, valid, Y);
 }
 
+// the same from values extracted once per tile (multi-pass kernel: the passes only differ in the table)
+template <int C, int VPL, bool TAIL>
+__device__ __forceinline__ void lut_groups_x(const uint32_t (&x)[VPL], const uint8_t *table, int valid, uint32_t (&Y)[VPL / 8][2])
+{
+#pragma unroll
+    for (int g = 0; g < VPL / 8; g++) {
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t m = lut_lookup<C, 0>(table, x[8 * g + i]);
+            if constexpr (TAIL) m = (8 * g + i < valid) ? m : 0u;
+            if (i < 4)
+                lo |= m << (8 * i);
+            else
+                hi |= m << (8 * (i - 4));
+        }
+        transpose8x8(lo, hi);
+        Y[g][0] = lo;
+        Y[g][1] = hi;
+    }
+}
+
+template <int C, int VPL, int K, int NW> __device__ __forceinline__ void extract_all(const uint32_t (&w)[NW], uint32_t (&x)[VPL])
+{
+    x[K] = extract<C, K, NW>(w);
+    if constexpr (K + 1 < VPL) extract_all<C, VPL, K + 1, NW>(w, x);
+}
+
 // per-key bitmap words of the lane: out[q][j] = bytes q of Y[4j..4j+3]
 template <int VPL> __device__ __forceinline__ void lut_gather_keys(const uint32_t (&Y)[VPL / 8][2], uint32_t (&out)[8][VPL / 32])
 {
@@ -788,7 +847,8 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
     constexpr int AUX = AUX_ & 15;
     constexpr int NRES = LAYOUT == 0 ? 8 * WORDS : GROUPS * 2; // result dwords per lane, tile and pass
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
-    __shared__ __attribute__((aligned(16))) uint8_t lut[(MULTI ? kLutMaxPasses : 1) * L::TABLE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lut_static[MULTI ? 16 : L::TABLE_BYTES];
+    uint8_t *const lut = MULTI ? mi355_dyn_lds : lut_static; // MULTI: npass * TABLE_BYTES dynamic bytes
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -849,13 +909,11 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                 }
             } else {
                 const uint32_t nk = (P - pass * 8) < 8 ? (P - pass * 8) : 8;
-                const bool whole = nk == 8 && (P & 7) == 0;
 #pragma unroll
                 for (int g = 0; g < GROUPS; g++) {
                     uint8_t *dst = a.out + (g0 + g) * P + pass * 8;
-                    if (whole) {
-                        u32x2 v = {res[2 * g], res[2 * g + 1]};
-                        *(u32x2 *)dst = v;
+                    if (nk == 8) {
+                        store8_unaligned(dst, res[2 * g], res[2 * g + 1]);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 8; q++)
@@ -881,18 +939,25 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
         const uint64_t next = tile + stride;
         if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
         const bool full = tile < tc.nfull;
+        uint32_t xs[MULTI ? VPL : 1];
+        if constexpr (MULTI) extract_all<C, VPL, 0, G::LANE_DWORDS>(w, xs);
 
         for (uint32_t pass = 0; pass < npass; pass++) {
             const uint8_t *table = lut + pass * L::TABLE_BYTES;
             uint32_t Y[GROUPS][2];
             uint32_t out[8][WORDS];
             if (full) {
-                lut_groups<C, VPL, 0, false, G::LANE_DWORDS>(w, table, VPL, Y);
-                lut_gather_keys<VPL>(Y, out);
+                if constexpr (MULTI)
+                    lut_groups_x<C, VPL, false>(xs, table, VPL, Y);
+                else
+                    lut_groups<C, VPL, 0, false, G::LANE_DWORDS>(w, table, VPL, Y);
+                if (LAYOUT == 0 || a.hits) lut_gather_keys<VPL>(Y, out);
+                if (a.hits) {
 #pragma unroll
-                for (int q = 0; q < 8; q++)
+                    for (int q = 0; q < 8; q++)
 #pragma unroll
-                    for (int j = 0; j < WORDS; j++) hits[q] += __builtin_popcount(out[q][j]);
+                        for (int j = 0; j < WORDS; j++) hits[q] += __builtin_popcount(out[q][j]);
+                }
                 uint32_t res[NRES];
                 if constexpr (LAYOUT == 0) {
 #pragma unroll
@@ -922,7 +987,10 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                 const int64_t left = (int64_t)(tc.n - tile * G::TILE_VALUES) - (int64_t)lane * VPL;
                 const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
                 const int nbytes = (valid + 7) / 8;
-                lut_groups<C, VPL, 0, true, G::LANE_DWORDS>(w, table, valid, Y);
+                if constexpr (MULTI)
+                    lut_groups_x<C, VPL, true>(xs, table, valid, Y);
+                else
+                    lut_groups<C, VPL, 0, true, G::LANE_DWORDS>(w, table, valid, Y);
                 lut_gather_keys<VPL>(Y, out);
 #pragma unroll
                 for (int q = 0; q < 8; q++) {

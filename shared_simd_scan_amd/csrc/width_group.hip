@@ -35,6 +35,13 @@ inline int scan_bpc(int occ_bpc, int tile_bytes, const LaunchReq &r)
     return want < occ_bpc ? want : occ_bpc;
 }
 
+// the multi-pass LUT kernel needs ceil(P/8) tables next to the block's four tiles in the CU's 160 KiB of LDS
+template <int C, int VPL> bool lut_fits(uint32_t P)
+{
+    const size_t tables = (size_t)((P + 7) / 8) * LutGeom<C>::TABLE_BYTES;
+    return tables + 4 * ScanGeom<C, VPL>::LDS_BYTES + 256 <= 160 * 1024;
+}
+
 template <int C, int MODE> void launch_scan(const LaunchReq &r)
 {
     constexpr int VPL = scan_vpl(C, MODE);
@@ -76,15 +83,20 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, false>), dim3(grid_for(ntiles, lut_bpc(bpc), r.num_cus)),
                                    dim3(kBlockThreads), 0, r.stream, r.scan);
             }
-        } else if (P <= 8 * (uint32_t)kLutMaxPasses) { // lookup tables for up to 64 keys, pass by pass
+        } else if (lut_fits<C, VPL>(P)) { // one lookup table per pass of 8 keys, in dynamic LDS
+            const size_t dyn = (size_t)((P + 7) / 8) * LutGeom<C>::TABLE_BYTES;
             if (linear) {
-                static const int bpc = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 1, true>);
-                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, true>), dim3(grid_for(ntiles, lut_bpc(bpc), r.num_cus)),
-                                   dim3(kBlockThreads), 0, r.stream, r.scan);
+                static const bool attr = ((void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 2, VPL, 1, true>,
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4 * G::LDS_BYTES - 256), true);
+                (void)attr;
+                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, true>), dim3(grid_for(ntiles, lut_bpc(8), r.num_cus)),
+                                   dim3(kBlockThreads), dyn, r.stream, r.scan);
             } else {
-                static const int bpc = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 0, true>);
-                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, true>), dim3(grid_for(ntiles, lut_bpc(bpc), r.num_cus)),
-                                   dim3(kBlockThreads), 0, r.stream, r.scan);
+                static const bool attr = ((void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 2, VPL, 0, true>,
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4 * G::LDS_BYTES - 256), true);
+                (void)attr;
+                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, true>), dim3(grid_for(ntiles, lut_bpc(8), r.num_cus)),
+                                   dim3(kBlockThreads), dyn, r.stream, r.scan);
             }
         } else { // more keys than the tables hold: compare chain, ceil(P/8) passes over the registers
             static const int bpc = blocks_per_cu(shared_general_kernel<C, 2, VPL>);

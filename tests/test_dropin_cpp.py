@@ -35,3 +35,37 @@ def test_reference_unit_tests_pass_through_the_dropin_header():
     assert res.returncode == 0, res.stdout + res.stderr
     assert "All tests passed" in res.stdout
     assert "not supported for 3 predicate keys!" in res.stderr
+
+
+CLI = os.path.join(ROOT, "cli", "shared_simd_scan_mi355")
+
+
+def parse_output(output):
+    """the parsing rule of the reference's scripts/prepare_shared_scan_results.py:14-20, restated"""
+    rows = []
+    for line in output.splitlines():
+        if not line.startswith("*"):
+            continue
+        variant = line[2:].split(": ")[0]
+        avg_runtime_ms = line.split(": ")[1].split("; ")[0][:-2]
+        rows.append((variant, float(avg_runtime_ms)))
+    return rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["40", "3", "scan"], ["40", "3", "decompression"], ["40", "2", "sharedscan"],
+                                  ["40", "2", "sharedscan", "3"], ["11", "1", "sharedscan", "100"],
+                                  ["1", "1", "sharedscan", "512"]])
+def test_cli_mirrors_reference_bench_harness(args):
+    """cli/shared_simd_scan_mi355: the reference's command line (src/main.cpp:12-73), inputs, output format and
+    self-checks (src/benchmark.cpp) on the GPU engine"""
+    if not os.path.exists(CLI):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "shared_simd_scan_amd", "csrc"), "cli"], check=True)
+    res = subprocess.run([CLI] + args, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "mismatch" not in res.stdout, res.stdout
+    assert "finished benchmark" in res.stdout
+    rows = parse_output(res.stdout)
+    assert len(rows) >= 1 and all(ms > 0 for _, ms in rows)
+    n = int(args[0]) * (1 << 20) * 8 // 9
+    assert f"compressed input: {n} (" in res.stdout

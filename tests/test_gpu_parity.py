@@ -231,7 +231,7 @@ def test_ragged_sizes(O, eng, n, c):
     assert np.array_equal(bm0.cpu().numpy(), obm0) and int(hits0.item()) == oh0 == int((vals == 0).sum())
 
 
-@pytest.mark.parametrize("P", [1, 2, 3, 5, 8, 9, 16, 37, 128])
+@pytest.mark.parametrize("P", [1, 2, 3, 5, 8, 9, 16, 37, 64, 65, 128, 300, 1024])
 @pytest.mark.parametrize("layout", ["per_predicate", "linear"])
 def test_shared_scan_predicate_counts(O, eng, P, layout):
     n, c = 2 * 8192 + 77, 9
@@ -239,6 +239,31 @@ def test_shared_scan_predicate_counts(O, eng, P, layout):
     packed_host = col.data.cpu().numpy()
     keys = [int(v) for v in np.random.default_rng(P).integers(0, 1 << c, size=P)]
     keys[0] = 0  # the reference's own shared-scan bench uses keys 0..P-1 (src/benchmark.cpp:205-209)
+    out, hits = eng.shared_scan(keys, col, layout=layout)
+    oout, ohits = O.shared_scan_eq(packed_host, n, c, keys, layout)
+    nb = (n + 7) // 8
+    got = out.cpu().numpy()
+    if layout == "per_predicate":
+        got = got[:, :nb]
+    assert np.array_equal(got, oout)
+    assert np.array_equal(hits.cpu().numpy().astype(np.uint64), ohits)
+
+
+@pytest.mark.parametrize("c,P", [(5, 40), (10, 520), (12, 200), (17, 129), (25, 72), (32, 16), (32, 600)])
+@pytest.mark.parametrize("layout", ["per_predicate", "linear"])
+def test_shared_scan_wide_and_many_keys(O, eng, c, P, layout):
+    """digit tables (c > 10), tables that do not fit in LDS (c=32, P=600 -> compare-chain kernel), duplicate and
+    out-of-range keys"""
+    n = 8192 + 4096 + 333
+    vals, col = make_column(O, eng, n, c, 900 + c + P)
+    packed_host = col.data.cpu().numpy()
+    rng = np.random.default_rng(c * 1000 + P)
+    keys = [int(vals[int(i)]) for i in rng.integers(0, n, size=P)]
+    keys[1] = keys[0]                      # duplicate key
+    if c < 31:
+        keys[2] = (1 << c) + 5             # out of range: matches nothing
+    keys[3] = -1
+    keys = [k if k < 2 ** 31 else k - 2 ** 32 for k in keys]
     out, hits = eng.shared_scan(keys, col, layout=layout)
     oout, ohits = O.shared_scan_eq(packed_host, n, c, keys, layout)
     nb = (n + 7) // 8
