@@ -25,6 +25,8 @@
  *     (reference behaviour, SURVEY 8c hazard 5).
  *   - *_dev functions take DEVICE pointers, enqueue on the context's stream and return without
  *     synchronising; the others take HOST pointers, copy in/out and return when done.
+ *   - a context binds one device and one stream and owns scratch the kernels use: calls on ONE context must not
+ *     run concurrently from several threads (use one context per thread / stream); different contexts are independent.
  *   - there is no CPU fallback: without a usable gfx950 device every compute entry point fails
  *     with MI355_E_NODEVICE / MI355_E_HIP.
  */

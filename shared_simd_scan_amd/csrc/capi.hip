@@ -79,8 +79,20 @@ typedef hipError_t (*group_fn)(const LaunchReq &);
 const group_fn kGroups[kNumGroups] = {launch_group_0, launch_group_1, launch_group_2, launch_group_3,
                                       launch_group_4, launch_group_5, launch_group_6, launch_group_7};
 
+// a context is bound to one device: make it current for this thread before touching it
+int bind(mi355_ctx *ctx)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) return fail(MI355_E_HIP, "hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e));
+    }
+    return MI355_OK;
+}
+
 int launch(mi355_ctx *ctx, LaunchReq &r)
 {
+    if (int rc = bind(ctx)) return rc;
     r.stream = ctx->stream;
     r.num_cus = ctx->num_cus;
     r.max_blocks_per_cu = ctx->max_blocks_per_cu;
@@ -250,6 +262,7 @@ static int pack_launch(mi355_ctx *ctx, int src, const void *values_dev, uint64_t
     if (((uintptr_t)packed_dev & 3) != 0) return fail(MI355_E_INVALID, "packed_dev must be 4-byte aligned");
     if ((src == kSrcU16 || src == kSrcU32) && !values_dev && n) return fail(MI355_E_INVALID, "values_dev is null");
     if (src == kSrcMod && param == 0) return fail(MI355_E_INVALID, "modulus 0");
+    if (int brc = bind(ctx)) return brc;
     PackArgs a;
     a.values = values_dev;
     a.n = n;

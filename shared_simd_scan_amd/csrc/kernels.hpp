@@ -477,9 +477,19 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void sca
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint8_t *lds_wave = lds[wave];
-    const TileCtx<C, VPL> tc(a.n);
-    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    TileCtx<C, VPL> tc(a.n);
+    uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
     uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    if constexpr (ABL == 5) {
+        // experiment (tools/tune_scan.hip): XCD-contiguous mapping -- blocks are dealt round-robin over the 8 XCDs,
+        // so give XCD x the x-th eighth of the tiles instead of every 8th block-row
+        const uint64_t per = (tc.ntiles + 7) / 8;
+        const uint64_t x = blockIdx.x & 7;
+        stride = (uint64_t)(gridDim.x / 8) * kWavesPerBlock;
+        tile = x * per + (uint64_t)(blockIdx.x / 8) * kWavesPerBlock + wave;
+        const uint64_t lim = (x + 1) * per < tc.ntiles ? (x + 1) * per : tc.ntiles;
+        tc.ntiles = tile < lim ? lim : tile; // this wave's range ends at its XCD's slice
+    }
     const uint32_t P = (MODE == kModeShared) ? a.nkeys : 1;
 
     unsigned long long stamp_c0 = 0, stamp_r0 = 0;
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void sca
         // the LDS tile must be fully read before the next DMA may overwrite it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (prev != ~0ull) { // every tile but a wave's last is a full tile
-            if constexpr (ABL == 0 || ABL == 4) {
+            if constexpr (ABL == 0 || ABL >= 4) {
                 uint8_t *dst = out_lane + prev * G::BITMAP_BYTES;
 #pragma unroll
                 for (int q = 0; q < NK; q++) {
@@ -555,7 +565,7 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void sca
         tile = next;
     }
     if (prev != ~0ull) {
-        if constexpr (ABL == 0 || ABL == 4) {
+        if constexpr (ABL == 0 || ABL >= 4) {
             uint8_t *dst = out_lane + prev * G::BITMAP_BYTES;
 #pragma unroll
             for (int q = 0; q < NK; q++) {

@@ -48,6 +48,29 @@ template <int UNROLL, int NT> __global__ __launch_bounds__(256) void read_kernel
     if (x == 0x12345678u) *sink = x;
 }
 
+// streaming-write and copy references (write ceiling / copy ceiling of the part)
+template <int NT> __global__ __launch_bounds__(256) void fill_kernel(u32x4 *p, uint64_t nvec)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    u32x4 v = {1u, 2u, 3u, (uint32_t)threadIdx.x};
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        if (NT)
+            __builtin_nontemporal_store(v, p + i);
+        else
+            p[i] = v;
+    }
+}
+template <int NT> __global__ __launch_bounds__(256) void copy_kernel(const u32x4 *src, u32x4 *dst, uint64_t nvec)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        if (NT)
+            __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+        else
+            dst[i] = src[i];
+    }
+}
+
 struct Variant {
     std::string name;
     std::function<void(int bpc, hipStream_t)> launch;
@@ -116,9 +139,10 @@ int main(int argc, char **argv)
                       hipLaunchKernelGGL((scan_kernel<C, kModeEq, AUX, VPL, ABL>), dim3(grid), dim3(kBlockThreads), 0, \
                                          s, sa);                                                                       \
                   },                                                                                                   \
-                  ScanGeom<C, VPL>::OCC, BYTES, (ABL) == 0 || (ABL) == 3})
+                  ScanGeom<C, VPL>::OCC, BYTES, (ABL) == 0 || (ABL) == 3 || (ABL) == 5})
     SCAN_VARIANT("vpl128 aux0", 128, 0, 0, scan_bytes);
     SCAN_VARIANT("vpl128 nt", 128, 2, 0, scan_bytes);
+    SCAN_VARIANT("vpl128 nt xcd-contig", 128, 2, 5, scan_bytes);
     SCAN_VARIANT("vpl128 nt ntstore", 128, 18, 0, scan_bytes);
     SCAN_VARIANT("vpl128 aux0 ntstore", 128, 16, 0, scan_bytes);
     SCAN_VARIANT("vpl64 nt ntstore", 64, 18, 0, scan_bytes);
@@ -192,6 +216,15 @@ int main(int argc, char **argv)
                       hipLaunchKernelGGL((read_kernel<8, 1>), dim3(bpc * cus), dim3(256), 0, s, (const u32x4 *)packed, nvec, sink);
                   }, 8, read_bytes, false});
 
+    {
+        const uint64_t wvec = (stride8 * 8) / 16; // the 8-bitmap buffer (~1 GB) as a write target
+        u32x4 *wbuf = (u32x4 *)bitmap8;
+        vs.push_back({"fill x4", [=](int bpc, hipStream_t s) { hipLaunchKernelGGL((fill_kernel<0>), dim3(bpc * cus), dim3(256), 0, s, wbuf, wvec); }, 8, wvec * 16.0, false});
+        vs.push_back({"fill x4 nt", [=](int bpc, hipStream_t s) { hipLaunchKernelGGL((fill_kernel<1>), dim3(bpc * cus), dim3(256), 0, s, wbuf, wvec); }, 8, wvec * 16.0, false});
+        const uint64_t cvec = std::min<uint64_t>(nvec, wvec);
+        vs.push_back({"copy x4", [=](int bpc, hipStream_t s) { hipLaunchKernelGGL((copy_kernel<0>), dim3(bpc * cus), dim3(256), 0, s, (const u32x4 *)packed, wbuf, cvec); }, 8, cvec * 32.0, false});
+        vs.push_back({"copy x4 nt", [=](int bpc, hipStream_t s) { hipLaunchKernelGGL((copy_kernel<1>), dim3(bpc * cus), dim3(256), 0, s, (const u32x4 *)packed, wbuf, cvec); }, 8, cvec * 32.0, false});
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
