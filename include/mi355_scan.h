@@ -138,6 +138,36 @@ MI355_API int mi355_shared_scan_eq_linear(mi355_ctx *ctx, const void *packed_hos
 MI355_API int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const int32_t *keys_host,
                              unsigned P, int layout, void *out_dev, uint64_t stride_bytes, uint64_t *hits_dev);
 
+/* ---- beyond the reference: the predicates and bitmap consumers its header only hints at
+ * (src/simd_scan.hpp:76-84 "predicate_low<=key<=predicate_high").  Device pointers only. ------- */
+#define MI355_CMP_EQ 0
+#define MI355_CMP_NE 1
+#define MI355_CMP_LT 2
+#define MI355_CMP_LE 3
+#define MI355_CMP_GT 4
+#define MI355_CMP_GE 5
+#define MI355_CMP_BETWEEN 6     /* a <= v <= b */
+#define MI355_CMP_NOT_BETWEEN 7 /* v < a or v > b */
+/* bitmap[i] = (v_i OP a [, b]) AND (and_mask_dev ? and_mask[i] : 1).  Unsigned comparison on the decoded value;
+ * a, b are clamped to the column's domain [0, 2^c).  and_mask_dev (nullable): a canonical bitmap of
+ * >= ceil(n/8) bytes, 16-byte aligned -- chains conjunctions over several columns without a separate AND pass. */
+MI355_API int mi355_scan_where_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int op, int64_t a, int64_t b,
+                                   const void *and_mask_dev, void *bitmap_dev, uint64_t *hits_dev);
+
+#define MI355_BITMAP_AND 0
+#define MI355_BITMAP_OR 1
+#define MI355_BITMAP_XOR 2
+#define MI355_BITMAP_ANDNOT 3 /* a & ~b */
+/* out = a OP b over n bits (canonical bitmaps, 16-byte aligned; out may alias a or b); count_dev (nullable) gets
+ * popcount(out) */
+MI355_API int mi355_bitmap_combine_dev(mi355_ctx *ctx, int op, const void *a_dev, const void *b_dev, void *out_dev, uint64_t n,
+                                       uint64_t *count_dev);
+MI355_API int mi355_bitmap_count_dev(mi355_ctx *ctx, const void *bitmap_dev, uint64_t n, uint64_t *count_dev);
+/* selection vector: writes first_row + i for every set bit i < n, ascending, into rowids_dev (at most `capacity`
+ * entries are written) and the total number of set bits into count_dev.  workspace: ctx-owned, grows on demand. */
+MI355_API int mi355_bitmap_to_rowids_dev(mi355_ctx *ctx, const void *bitmap_dev, uint64_t n, uint64_t first_row,
+                                         uint64_t *rowids_dev, uint64_t capacity, uint64_t *count_dev);
+
 /* ---- introspection used by bench.py / tests --------------------------------------------------- */
 /* name of the HIP kernel a given op dispatches to at width c ("scan_eq", "scan_range", "shared_scan",
  * "decompress", "pack"); returns NULL for unknown ops */

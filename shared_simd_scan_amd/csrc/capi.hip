@@ -30,6 +30,8 @@ struct mi355_ctx {
     unsigned long long *hits_scratch = nullptr; // host-pointer API: where the kernels deliver hit counts
     unsigned long long *kernel_scratch = nullptr; // kScratchWords words, all zero between launches (kernels.hpp hits_finalize)
     int32_t *keys_scratch = nullptr;            // 1024 + 8 keys
+    unsigned long long *rowid_ws = nullptr;     // chunk counts of mi355_bitmap_to_rowids_dev
+    size_t rowid_ws_entries = 0;
 };
 
 namespace {
@@ -172,6 +174,7 @@ int mi355_ctx_destroy(mi355_ctx *ctx)
     (void)hipFree(ctx->hits_scratch);
     (void)hipFree(ctx->kernel_scratch);
     (void)hipFree(ctx->keys_scratch);
+    (void)hipFree(ctx->rowid_ws);
     {
         std::lock_guard<std::mutex> lk(g_default_mu);
         if (g_default == ctx) g_default = nullptr;
@@ -450,6 +453,152 @@ int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n,
         r.scan.keys_dev = ctx->keys_scratch;
     }
     return launch(ctx, r);
+}
+
+/* ---- predicates and bitmap consumers beyond the reference ---- */
+int mi355_scan_where_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int op, int64_t a, int64_t b,
+                         const void *and_mask_dev, void *bitmap_dev, uint64_t *hits_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if ((rc = check_width(c))) return rc;
+    if (op < MI355_CMP_EQ || op > MI355_CMP_NOT_BETWEEN) return fail(MI355_E_INVALID, "unknown comparison %d", op);
+    if (n == 0) {
+        if (hits_dev) HIP_TRY(hipMemsetAsync(hits_dev, 0, sizeof(uint64_t), ctx->stream));
+        return MI355_OK;
+    }
+    if (!packed_dev || !bitmap_dev) return fail(MI355_E_INVALID, "null device pointer");
+    if (((uintptr_t)packed_dev & 15) || ((uintptr_t)bitmap_dev & 15) || ((uintptr_t)and_mask_dev & 15))
+        return fail(MI355_E_INVALID, "packed_dev, bitmap_dev and and_mask_dev must be 16-byte aligned");
+    // every comparison is an inclusive range [lo, hi] over the domain [0, vmax], possibly negated
+    const int64_t vmax = c == 32 ? 0xffffffffll : ((1ll << c) - 1);
+    int64_t lo = 0, hi = vmax;
+    bool invert = false, empty = false;
+    switch (op) {
+    case MI355_CMP_EQ: lo = hi = a; break;
+    case MI355_CMP_NE: lo = hi = a; invert = true; break;
+    case MI355_CMP_LT: hi = a - 1; break;
+    case MI355_CMP_LE: hi = a; break;
+    case MI355_CMP_GT: lo = a + 1; break;
+    case MI355_CMP_GE: lo = a; break;
+    case MI355_CMP_BETWEEN: lo = a; hi = b; break;
+    case MI355_CMP_NOT_BETWEEN: lo = a; hi = b; invert = true; break;
+    }
+    if (lo < 0) lo = 0;
+    if (hi > vmax) hi = vmax;
+    if (lo > hi) empty = true; // matches nothing (or, negated, everything)
+    LaunchReq r{};
+    r.op = kOpScanRange;
+    r.c = c;
+    r.scan.packed = (const uint8_t *)packed_dev;
+    r.scan.n = n;
+    r.scan.out = (uint8_t *)bitmap_dev;
+    r.scan.hits = (unsigned long long *)hits_dev;
+    r.scan.nkeys = 1;
+    r.scan.and_mask = (const uint8_t *)and_mask_dev;
+    r.scan.invert = invert ? 0xffffffffu : 0u;
+    if (empty) { // x - 1 <= 0 - ... : an impossible range: lo = 1, span = 0xffffffff - wraps; use lo > every value instead
+        r.scan.key[0] = 0xffffffffu; // t = x - lo is never <= span 0 unless x == 0xffffffff, which needs c == 32 ...
+        r.scan.key[1] = 0;
+        if (c == 32) { // ... so fold the empty case into the negation flag on the full range
+            r.scan.key[0] = 0;
+            r.scan.key[1] = 0xffffffffu;
+            r.scan.invert = invert ? 0u : 0xffffffffu;
+        }
+    } else {
+        r.scan.key[0] = (uint32_t)lo;
+        r.scan.key[1] = (uint32_t)(hi - lo);
+    }
+    return launch(ctx, r);
+}
+
+static int bitmap_launch(mi355_ctx *ctx, int op, const void *a, const void *b, void *out, uint64_t n, uint64_t *count_dev)
+{
+    if (int brc = bind(ctx)) return brc;
+    if (n == 0) {
+        if (count_dev) HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(uint64_t), ctx->stream));
+        return MI355_OK;
+    }
+    if (!a || (op != kBitCount && (!b || !out))) return fail(MI355_E_INVALID, "null device pointer");
+    if (((uintptr_t)a & 15) || ((uintptr_t)b & 15) || ((uintptr_t)out & 15))
+        return fail(MI355_E_INVALID, "bitmaps must be 16-byte aligned");
+    BitmapArgs g;
+    g.a = (const uint8_t *)a;
+    g.b = (const uint8_t *)b;
+    g.out = (uint8_t *)out;
+    g.nbytes = bitmap_bytes(n);
+    // partial counts go to the (all-zero) hit-count replicas of the context scratch, then to count_dev
+    g.count = count_dev ? ctx->kernel_scratch : nullptr;
+    uint64_t blocks = (g.nbytes / 16 + 255) / 256;
+    unsigned grid = (unsigned)(blocks < (uint64_t)ctx->num_cus * 4 ? (blocks ? blocks : 1) : (uint64_t)ctx->num_cus * 4);
+    switch (op) {
+    case kBitAnd: hipLaunchKernelGGL(bitmap_kernel<kBitAnd>, dim3(grid), dim3(256), 0, ctx->stream, g); break;
+    case kBitOr: hipLaunchKernelGGL(bitmap_kernel<kBitOr>, dim3(grid), dim3(256), 0, ctx->stream, g); break;
+    case kBitXor: hipLaunchKernelGGL(bitmap_kernel<kBitXor>, dim3(grid), dim3(256), 0, ctx->stream, g); break;
+    case kBitAndNot: hipLaunchKernelGGL(bitmap_kernel<kBitAndNot>, dim3(grid), dim3(256), 0, ctx->stream, g); break;
+    case kBitCount: hipLaunchKernelGGL(bitmap_kernel<kBitCount>, dim3(grid), dim3(256), 0, ctx->stream, g); break;
+    default: return fail(MI355_E_INVALID, "unknown bitmap op %d", op);
+    }
+    if (count_dev)
+        hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->kernel_scratch, (unsigned long long *)count_dev);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+
+int mi355_bitmap_combine_dev(mi355_ctx *ctx, int op, const void *a_dev, const void *b_dev, void *out_dev, uint64_t n,
+                             uint64_t *count_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if (op < MI355_BITMAP_AND || op > MI355_BITMAP_ANDNOT) return fail(MI355_E_INVALID, "unknown bitmap op %d", op);
+    return bitmap_launch(ctx, op, a_dev, b_dev, out_dev, n, count_dev);
+}
+
+int mi355_bitmap_count_dev(mi355_ctx *ctx, const void *bitmap_dev, uint64_t n, uint64_t *count_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if (!count_dev) return fail(MI355_E_INVALID, "count_dev is null");
+    return bitmap_launch(ctx, kBitCount, bitmap_dev, nullptr, nullptr, n, count_dev);
+}
+
+int mi355_bitmap_to_rowids_dev(mi355_ctx *ctx, const void *bitmap_dev, uint64_t n, uint64_t first_row, uint64_t *rowids_dev,
+                               uint64_t capacity, uint64_t *count_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if ((rc = bind(ctx))) return rc;
+    if (!count_dev) return fail(MI355_E_INVALID, "count_dev is null");
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(uint64_t), ctx->stream));
+        return MI355_OK;
+    }
+    if (!bitmap_dev || (!rowids_dev && capacity)) return fail(MI355_E_INVALID, "null device pointer");
+    if ((uintptr_t)bitmap_dev & 3) return fail(MI355_E_INVALID, "bitmap_dev must be 4-byte aligned");
+    RowidArgs g;
+    g.bitmap = (const uint8_t *)bitmap_dev;
+    g.nbytes = bitmap_bytes(n);
+    g.first_row = first_row;
+    g.nchunks = (g.nbytes + kRowidChunk - 1) / kRowidChunk;
+    if (ctx->rowid_ws_entries < g.nchunks + 1) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->rowid_ws) HIP_TRY(hipFree(ctx->rowid_ws));
+        ctx->rowid_ws = nullptr;
+        ctx->rowid_ws_entries = 0;
+        HIP_TRY(hipMalloc((void **)&ctx->rowid_ws, (g.nchunks + 1) * sizeof(unsigned long long)));
+        ctx->rowid_ws_entries = g.nchunks + 1;
+    }
+    g.chunk_counts = ctx->rowid_ws;
+    g.rowids = rowids_dev;
+    g.capacity = capacity;
+    uint64_t blocks = (g.nchunks + 3) / 4;
+    unsigned grid = (unsigned)(blocks < (uint64_t)ctx->num_cus * 8 ? blocks : (uint64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(rowid_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL(rowid_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, g);
+    hipLaunchKernelGGL(rowid_write_kernel, dim3(grid), dim3(256), 0, ctx->stream, g);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(count_dev, g.chunk_counts + g.nchunks, sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    return MI355_OK;
 }
 
 /* ---- host-pointer (copying, synchronous) flavours: the drop-in path ---- */

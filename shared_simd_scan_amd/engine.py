@@ -147,6 +147,43 @@ class ScanEngine:
                                          hits.data_ptr()))
         return bitmap, hits
 
+    # ---- beyond the reference: general comparisons, conjunctions, bitmap consumers -----
+    _CMP = {"==": 0, "!=": 1, "<": 2, "<=": 3, ">": 4, ">=": 5, "between": 6, "not_between": 7}
+    _BOP = {"and": 0, "or": 1, "xor": 2, "andnot": 3}
+
+    def scan_where(self, op: str, a: int, col: PackedColumn, b: int = 0, and_mask: Optional[torch.Tensor] = None,
+                   bitmap: Optional[torch.Tensor] = None, hits: Optional[torch.Tensor] = None):
+        """bitmap[i] = (value_i OP a [, b]) [& and_mask[i]]; op in == != < <= > >= between not_between."""
+        if bitmap is None:
+            bitmap = self.alloc_bitmap(col.n)
+        if hits is None:
+            hits = torch.empty(1, dtype=torch.int64, device=self._dev)
+        check(lib().mi355_scan_where_dev(self._ctx, col.data.data_ptr(), col.n, col.c, self._CMP[op], int(a), int(b),
+                                         and_mask.data_ptr() if and_mask is not None else None, bitmap.data_ptr(),
+                                         hits.data_ptr()))
+        return bitmap, hits
+
+    def bitmap_combine(self, op: str, a: torch.Tensor, b: torch.Tensor, n: int, out: Optional[torch.Tensor] = None):
+        if out is None:
+            out = self.alloc_bitmap(n)
+        count = torch.empty(1, dtype=torch.int64, device=self._dev)
+        check(lib().mi355_bitmap_combine_dev(self._ctx, self._BOP[op], a.data_ptr(), b.data_ptr(), out.data_ptr(), n,
+                                             count.data_ptr()))
+        return out, count
+
+    def bitmap_count(self, bitmap: torch.Tensor, n: int) -> torch.Tensor:
+        count = torch.empty(1, dtype=torch.int64, device=self._dev)
+        check(lib().mi355_bitmap_count_dev(self._ctx, bitmap.data_ptr(), n, count.data_ptr()))
+        return count
+
+    def bitmap_to_rowids(self, bitmap: torch.Tensor, n: int, capacity: int, first_row: int = 0):
+        """-> (int64 row ids [capacity], count int64[1]); ids beyond `capacity` are dropped, count is the total."""
+        rowids = torch.empty(max(capacity, 1), dtype=torch.int64, device=self._dev)
+        count = torch.empty(1, dtype=torch.int64, device=self._dev)
+        check(lib().mi355_bitmap_to_rowids_dev(self._ctx, bitmap.data_ptr(), n, first_row, rowids.data_ptr(), capacity,
+                                               count.data_ptr()))
+        return rowids, count
+
     # ---- shared scans (src/simd_scan_shared.cpp, src/simd_scan_shared_linear.cpp) -----------------
     def shared_scan(self, keys: Sequence[int], col: PackedColumn, layout: str = "per_predicate",
                     out: Optional[torch.Tensor] = None, hits: Optional[torch.Tensor] = None):

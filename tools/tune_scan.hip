@@ -143,6 +143,7 @@ int main(int argc, char **argv)
     SCAN_VARIANT("vpl128 aux0", 128, 0, 0, scan_bytes);
     SCAN_VARIANT("vpl128 nt", 128, 2, 0, scan_bytes);
     SCAN_VARIANT("vpl128 nt xcd-contig", 128, 2, 5, scan_bytes);
+    SCAN_VARIANT("vpl128 nt sc1store", 128, 34, 0, scan_bytes);
     SCAN_VARIANT("vpl128 nt ntstore", 128, 18, 0, scan_bytes);
     SCAN_VARIANT("vpl128 aux0 ntstore", 128, 16, 0, scan_bytes);
     SCAN_VARIANT("vpl64 nt ntstore", 64, 18, 0, scan_bytes);
