@@ -124,7 +124,7 @@ static void bench_scan(mi355_ctx *ctx, size_t data_size, size_t reps)
     mi355_dev_free(ctx, hits);
 }
 
-static void bench_shared_scan(mi355_ctx *ctx, size_t data_size, size_t reps, int P)
+static void bench_shared_scan(mi355_ctx *ctx, size_t data_size, size_t reps, int P, bool want_hits)
 {
     const unsigned c = 9;
     const size_t n = data_size * 8 / c;
@@ -132,7 +132,8 @@ static void bench_shared_scan(mi355_ctx *ctx, size_t data_size, size_t reps, int
         std::cerr << "predicate_count must be 1..1024" << std::endl;
         std::exit(1);
     }
-    // (the reference's shared scans return no hit counts, src/simd_scan.hpp:102-120: none are requested here)
+    // (the reference's shared scans return no hit counts, src/simd_scan.hpp:102-120: none are requested unless the
+    // optional 5th argument is "hits")
     std::vector<int32_t> keys(P);
     for (int i = 0; i < P; i++) keys[i] = i; // src/benchmark.cpp:205-209
     const size_t nb = (n + 7) / 8, stride = (nb + 15) / 16 * 16;
@@ -146,7 +147,7 @@ static void bench_shared_scan(mi355_ctx *ctx, size_t data_size, size_t reps, int
     std::cout << "compressed input: " << n << " (" << data_size << " bytes)" << std::endl;
     std::cout << "predicate key count: " << P << std::endl;
     auto ms = time_reps(ctx, reps, [&] {
-        CHECK(mi355_shared_scan_eq_dev(ctx, packed, n, c, keys.data(), P, MI355_LAYOUT_PER_PREDICATE, out, stride, nullptr));
+        CHECK(mi355_shared_scan_eq_dev(ctx, packed, n, c, keys.data(), P, MI355_LAYOUT_PER_PREDICATE, out, stride, want_hits ? (uint64_t *)hits : nullptr));
     });
     print_numbers("mi355x hip, standard", ms);
     // check_scan_result per predicate (the reference has these checks commented out, src/benchmark.cpp:227)
@@ -160,7 +161,7 @@ static void bench_shared_scan(mi355_ctx *ctx, size_t data_size, size_t reps, int
             }
     }
     ms = time_reps(ctx, reps, [&] {
-        CHECK(mi355_shared_scan_eq_dev(ctx, packed, n, c, keys.data(), P, MI355_LAYOUT_LINEAR, out, 0, nullptr));
+        CHECK(mi355_shared_scan_eq_dev(ctx, packed, n, c, keys.data(), P, MI355_LAYOUT_LINEAR, out, 0, want_hits ? (uint64_t *)hits : nullptr));
     });
     print_numbers("mi355x hip, linear, standard", ms);
     std::cout << "finished benchmark" << std::endl;
@@ -187,7 +188,7 @@ int main(int argc, char **argv)
     } else if (strcmp(bench_name, "scan") == 0) {
         bench_scan(ctx, data_size, repetitions);
     } else if (strcmp(bench_name, "sharedscan") == 0) {
-        bench_shared_scan(ctx, data_size, repetitions, argc > 4 ? atoi(argv[4]) : 8);
+        bench_shared_scan(ctx, data_size, repetitions, argc > 4 ? atoi(argv[4]) : 8, argc > 5 && strcmp(argv[5], "hits") == 0);
     } else if (strcmp(bench_name, "memory") == 0) {
         std::cout << "memory: host DRAM copy probes (src/benchmark_misc.cpp) are not part of the scan path" << std::endl;
     } else {

@@ -420,6 +420,38 @@ __device__ __forceinline__ void hits_finalize(const ScanArgs &a, uint32_t P, int
     }
 }
 
+// Multi-pass shared scans (P > 8) count hits per tile and pass.  Doing that with a wave reduction and a global
+// atomic per key stalled the pipeline (the atomics sit in front of the next tile's vmcnt wait).  Instead: the
+// lane's 8 counts (<= 64 each) are packed four to a dword in 16-bit fields, two wave reductions sum them
+// (<= 4096 per field), lane 0 adds the 8 sums to per-block counters in LDS, and the block flushes those to the
+// replicated global totals once, at the end.
+__device__ __forceinline__ void block_hits_add8(uint32_t *s_hits, uint32_t kbase, uint32_t P, const uint32_t (&cnt)[8], int lane)
+{
+    uint32_t p0 = cnt[0] | (cnt[1] << 16), p1 = cnt[2] | (cnt[3] << 16), p2 = cnt[4] | (cnt[5] << 16), p3 = cnt[6] | (cnt[7] << 16);
+    p0 = wave_sum(p0);
+    p1 = wave_sum(p1);
+    p2 = wave_sum(p2);
+    p3 = wave_sum(p3);
+    if (lane == 0) {
+        const uint32_t v[8] = {p0 & 0xffff, p0 >> 16, p1 & 0xffff, p1 >> 16, p2 & 0xffff, p2 >> 16, p3 & 0xffff, p3 >> 16};
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (kbase + q < P && v[q]) atomicAdd(&s_hits[kbase + q], v[q]);
+    }
+}
+
+// every thread of the block calls this once, after its last block_hits_add8 and before hits_finalize
+__device__ __forceinline__ void block_hits_flush(const ScanArgs &a, uint32_t *s_hits, uint32_t P)
+{
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) {
+        const uint32_t v = s_hits[k];
+        if (v)
+            __hip_atomic_fetch_add(a.scratch + (blockIdx.x % kHitSlots) * kMaxKeys + k, (unsigned long long)v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---- the scan kernel ------------------------------------------------------------------------
 // Per wave, per tile:  wait for the tile's DMA -> ds_read the lane's run into VGPRs -> (LDS is free)
 // store the PREVIOUS tile's bitmap words, then issue the NEXT tile's DMA -> decode/compare in registers.
@@ -469,19 +501,22 @@ template <int C, int VPL> struct TileCtx {
     }
 };
 
-template <int C, int MODE, int AUX_, int VPL, int ABL = 0>
-__global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void scan_kernel(ScanArgs a)
+// DEPTH: tiles of DMA in flight per wave ahead of the one being decoded (1: one LDS buffer per wave; 2: two buffers,
+// the wait for tile t is `vmcnt(DMA_INSTRS)` = everything older than the DMA of tile t+1).
+template <int C, int MODE, int AUX_, int VPL, int ABL = 0, int DEPTH = 1>
+__global__ __launch_bounds__(kBlockThreads, (DEPTH == 1 ? scan_occ<C, VPL, MODE>() : 1)) void scan_kernel(ScanArgs a)
 {
     using G = ScanGeom<C, VPL>;
     constexpr int NK = (MODE == kModeShared) ? kMaxKeysPerPass : 1;
     constexpr int WORDS = G::WORDS;
     constexpr int AUX = AUX_ & 15;
     constexpr int NTS = (AUX_ & 32) ? 2 : ((AUX_ & 16) ? 1 : 0);
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+    static_assert(DEPTH == 1 || DEPTH == 2, "DEPTH");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][DEPTH][G::LDS_BYTES];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint8_t *lds_wave = lds[wave];
+    uint8_t *lds_wave = lds[wave][0];
     TileCtx<C, VPL> tc(a.n);
     uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
     uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -517,10 +552,24 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void sca
     uint32_t res[NK][WORDS];
     uint64_t prev = ~0ull; // tile whose results sit in `res`, not yet stored
     if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+    if constexpr (DEPTH == 2) {
+        if (tile + stride < tc.ntiles) tc.template issue<AUX>(a.packed, tile + stride, lds_wave + G::LDS_BYTES, lane);
+    }
+    uint32_t parity = 0; // DEPTH 2: which of the wave's two LDS buffers holds the current tile
     while (tile < tc.ntiles) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint8_t *cur = lds_wave;
+        if constexpr (DEPTH == 2) {
+            cur = lds_wave + parity * G::LDS_BYTES;
+            // tile t+1's DMA (DMA_INSTRS instructions, all issued: it is a full tile) may stay in flight
+            if (tile + stride < tc.nfull)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::DMA_INSTRS) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         uint32_t w[G::LANE_DWORDS];
-        if constexpr (ABL != 1) read_lane_data<C, VPL>(lds_wave, lane, w);
+        if constexpr (ABL != 1) read_lane_data<C, VPL>(cur, lane, w);
         // the LDS tile must be fully read before the next DMA may overwrite it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (prev != ~0ull) { // every tile but a wave's last is a full tile
@@ -534,7 +583,12 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, MODE>())) void sca
             }
         }
         const uint64_t next = tile + stride;
-        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        if constexpr (DEPTH == 2) {
+            if (next + stride < tc.ntiles) tc.template issue<AUX>(a.packed, next + stride, cur, lane);
+            parity ^= 1;
+        } else {
+            if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        }
 
         if constexpr (ABL == 1) {
 #pragma unroll
@@ -646,13 +700,16 @@ __device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&r)[4], uint3
 // per-predicate or linear output (byte of 8-value group g and key k at g*P + k,
 // src/simd_scan_shared_linear.cpp:57).  The tile's DMA is prefetched as above; results are stored pass by pass.
 template <int C, int AUX_, int VPL>
-__global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, kModeShared>())) void shared_general_kernel(ScanArgs a)
+__global__ __launch_bounds__(kBlockThreads) void shared_general_kernel(ScanArgs a)
 {
     using G = ScanGeom<C, VPL>;
     constexpr int NK = kMaxKeysPerPass;
     constexpr int WORDS = G::WORDS;
     constexpr int AUX = AUX_ & 15;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+    __shared__ uint32_t s_hits[kMaxKeys];
+    for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxKeys; k += kBlockThreads) s_hits[k] = 0;
+    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -686,9 +743,11 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, kModeShared>())) v
             }
             uint32_t res[NK][WORDS];
             decode_words<C, VPL, 0, NK, kModeShared, G::LANE_DWORDS>(w, res, key);
+            uint32_t cnts[8];
 #pragma unroll
             for (int q = 0; q < NK; q++) {
                 const uint32_t k = pass * kMaxKeysPerPass + q;
+                cnts[q] = 0;
                 if (k < P) {
                     uint32_t cnt = 0;
                     if (a.layout == 0) {
@@ -707,9 +766,10 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, kModeShared>())) v
 #pragma unroll
                         for (int j = 0; j < WORDS; j++) cnt += __builtin_popcount(res[q][j]);
                     }
-                    if (a.hits) hits_add(a, k, wave_sum(cnt), lane);
+                    cnts[q] = cnt;
                 }
             }
+            if (a.hits) block_hits_add8(s_hits, pass * kMaxKeysPerPass, P, cnts, lane);
             if (a.layout != 0 && full) {
                 // linear: the 8 keys of this pass are 8 consecutive bytes of every 8-value group: gather them
                 // with 4x4 byte transposes (key-major words -> group-major key bytes) and store 8 bytes per group
@@ -738,6 +798,7 @@ __global__ __launch_bounds__(kBlockThreads, (scan_occ<C, VPL, kModeShared>())) v
         }
         tile = next;
     }
+    if (a.hits) block_hits_flush(a, s_hits, P);
     hits_finalize(a, P, lane);
 }
 
@@ -888,6 +949,9 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t lut_static[MULTI ? 16 : L::TABLE_BYTES];
     uint8_t *const lut = MULTI ? mi355_dyn_lds : lut_static; // MULTI: npass * TABLE_BYTES dynamic bytes
+    __shared__ uint32_t s_hits[MULTI ? kMaxKeys : 1];          // MULTI: per-block hit counters (block_hits_add8)
+    if constexpr (MULTI)
+        for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxKeys; k += kBlockThreads) s_hits[k] = 0;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -981,7 +1045,45 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
         uint32_t xs[MULTI ? VPL : 1];
         if constexpr (MULTI) extract_all<C, VPL, 0, G::LANE_DWORDS>(w, xs);
 
-        for (uint32_t pass = 0; pass < npass; pass++) {
+        if constexpr (MULTI && LAYOUT == 1) {
+            // Linear layout, many keys: row g (8-value group) holds P bytes, and a lane's 8 rows are contiguous.
+            // Walk the rows in order and, inside a row, the passes in order, so every row is written start to end
+            // in one go (the pass-major order revisits each 128-B line npass times: 10x slower at P = 512).
+            if (full) {
+                const uint64_t g0 = tile * G::BITMAP_BYTES + (uint64_t)lane * GROUPS;
+#pragma unroll
+                for (int g = 0; g < GROUPS; g++) {
+                    uint8_t *row = a.out + (g0 + g) * P;
+                    uint32_t xg[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) xg[i] = xs[8 * g + i];
+                    for (uint32_t pass = 0; pass < npass; pass++) {
+                        const uint8_t *table = lut + pass * L::TABLE_BYTES;
+                        uint32_t lo = 0, hi = 0;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const uint32_t m = lut_lookup<C, 0>(table, xg[i]);
+                            if (i < 4)
+                                lo |= m << (8 * i);
+                            else
+                                hi |= m << (8 * (i - 4));
+                        }
+                        transpose8x8(lo, hi);
+                        const uint32_t nk = (P - pass * 8) < 8 ? (P - pass * 8) : 8;
+                        if (nk == 8) {
+                            store8_unaligned(row + pass * 8, lo, hi);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 8; q++)
+                                if ((uint32_t)q < nk) row[pass * 8 + q] = (uint8_t)((q < 4 ? lo : hi) >> (8 * (q & 3)));
+                        }
+                    }
+                }
+            }
+        }
+
+        // pass-major loop: per-predicate stores, hit counts, tail tiles (and everything for one-pass scans)
+        for (uint32_t pass = 0; pass < npass && (!(MULTI && LAYOUT == 1) || !full || a.hits); pass++) {
             const uint8_t *table = lut + pass * L::TABLE_BYTES;
             uint32_t Y[GROUPS][2];
             uint32_t out[8][WORDS];
@@ -1013,13 +1115,12 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                     prev = tile;
                 } else {
                     if (a.hits) {
+                        block_hits_add8(s_hits, pass * 8, P, hits, lane);
 #pragma unroll
-                        for (int q = 0; q < 8; q++) {
-                            if (pass * 8 + q < P) hits_add(a, pass * 8 + q, wave_sum(hits[q]), lane);
-                            hits[q] = 0;
-                        }
+                        for (int q = 0; q < 8; q++) hits[q] = 0;
                     }
-                    store_full(tile, pass, res);
+                    // LAYOUT 1: the rows are written group by group below (each row's P bytes back to back)
+                    if constexpr (LAYOUT == 0) store_full(tile, pass, res);
                 }
             } else {
                 // tail tile: lookups of values >= n are zeroed; the bitmap is written byte-exact
@@ -1031,17 +1132,19 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                 else
                     lut_groups<C, VPL, 0, true, G::LANE_DWORDS>(w, table, valid, Y);
                 lut_gather_keys<VPL>(Y, out);
+                uint32_t tcnt[8];
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const uint32_t k = pass * 8 + q;
+                    tcnt[q] = 0;
                     if (k < P) {
                         uint32_t cnt = 0;
 #pragma unroll
                         for (int j = 0; j < WORDS; j++) cnt += __builtin_popcount(out[q][j]);
                         if constexpr (!MULTI)
                             hits[q] += cnt;
-                        else if (a.hits)
-                            hits_add(a, k, wave_sum(cnt), lane);
+                        else
+                            tcnt[q] = cnt;
                         uint8_t *dst = LAYOUT == 0
                                            ? a.out + (uint64_t)k * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4)
                                            : a.out + (tile * G::BITMAP_BYTES + (uint64_t)lane * GROUPS) * P + k;
@@ -1051,9 +1154,15 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                             if (b < nbytes) dst[(uint64_t)b * bstride] = (uint8_t)(out[q][b >> 2] >> (8 * (b & 3)));
                     }
                 }
+                if constexpr (MULTI) {
+                    if (a.hits) block_hits_add8(s_hits, pass * 8, P, tcnt, lane);
+                }
             }
         }
         tile = next;
+    }
+    if constexpr (MULTI) {
+        if (a.hits) block_hits_flush(a, s_hits, P);
     }
     if constexpr (!MULTI) {
         if (prev != ~0ull) store_full(prev, 0, resp);

@@ -35,11 +35,14 @@ inline int scan_bpc(int occ_bpc, int tile_bytes, const LaunchReq &r)
     return want < occ_bpc ? want : occ_bpc;
 }
 
-// the multi-pass LUT kernel needs ceil(P/8) tables next to the block's four tiles in the CU's 160 KiB of LDS
+// static LDS of the multi-pass LUT kernel: four tiles, the per-block hit counters, ticket word and slack
+template <int C, int VPL> constexpr size_t lut_static_lds() { return 4 * ScanGeom<C, VPL>::LDS_BYTES + kMaxKeys * 4 + 512; }
+
+// the multi-pass LUT kernel needs ceil(P/8) tables next to that in the CU's 160 KiB of LDS
 template <int C, int VPL> bool lut_fits(uint32_t P)
 {
     const size_t tables = (size_t)((P + 7) / 8) * LutGeom<C>::TABLE_BYTES;
-    return tables + 4 * ScanGeom<C, VPL>::LDS_BYTES + 256 <= 160 * 1024;
+    return tables + lut_static_lds<C, VPL>() <= 160 * 1024;
 }
 
 template <int C, int MODE> void launch_scan(const LaunchReq &r)
@@ -87,13 +90,13 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
             const size_t dyn = (size_t)((P + 7) / 8) * LutGeom<C>::TABLE_BYTES;
             if (linear) {
                 static const bool attr = ((void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 2, VPL, 1, true>,
-                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4 * G::LDS_BYTES - 256), true);
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - lut_static_lds<C, VPL>())), true);
                 (void)attr;
                 hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, true>), dim3(grid_for(ntiles, lut_bpc(8), r.num_cus)),
                                    dim3(kBlockThreads), dyn, r.stream, r.scan);
             } else {
                 static const bool attr = ((void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 2, VPL, 0, true>,
-                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4 * G::LDS_BYTES - 256), true);
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - lut_static_lds<C, VPL>())), true);
                 (void)attr;
                 hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, true>), dim3(grid_for(ntiles, lut_bpc(8), r.num_cus)),
                                    dim3(kBlockThreads), dyn, r.stream, r.scan);

@@ -143,6 +143,19 @@ int main(int argc, char **argv)
     SCAN_VARIANT("vpl128 aux0", 128, 0, 0, scan_bytes);
     SCAN_VARIANT("vpl128 nt", 128, 2, 0, scan_bytes);
     SCAN_VARIANT("vpl128 nt xcd-contig", 128, 2, 5, scan_bytes);
+#define SCAN_VARIANT_D2(NAME, VPL, AUX, BYTES)                                                                          \
+    vs.push_back({NAME,                                                                                                \
+                  [=](int bpc, hipStream_t s) {                                                                        \
+                      using G = ScanGeom<C, VPL>;                                                                      \
+                      uint64_t ntiles = (n + G::TILE_VALUES - 1) / G::TILE_VALUES;                                     \
+                      uint64_t want = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;                                  \
+                      unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)bpc * cus);                         \
+                      hipLaunchKernelGGL((scan_kernel<C, kModeEq, AUX, VPL, 0, 2>), dim3(grid), dim3(kBlockThreads), 0, \
+                                         s, sa);                                                                       \
+                  },                                                                                                   \
+                  2, BYTES, true})
+    SCAN_VARIANT_D2("vpl128 nt depth2", 128, 2, scan_bytes);
+    SCAN_VARIANT_D2("vpl64 nt depth2", 64, 2, scan_bytes);
     SCAN_VARIANT("vpl128 nt sc1store", 128, 34, 0, scan_bytes);
     SCAN_VARIANT("vpl128 nt ntstore", 128, 18, 0, scan_bytes);
     SCAN_VARIANT("vpl128 aux0 ntstore", 128, 16, 0, scan_bytes);
