@@ -154,6 +154,12 @@ MI355_API int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, u
 MI355_API int mi355_scan_where_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int op, int64_t a, int64_t b,
                                    const void *and_mask_dev, void *bitmap_dev, uint64_t *hits_dev);
 
+/* bitmap[i] = (v_i IN {keys[0..P-1]}) AND (and_mask ? and_mask[i] : 1), negated when `negate` != 0 (NOT IN).
+ * 1 <= P <= 1024; keys outside [0, 2^c) match nothing.  c <= 16: bitset lookup, cost independent of P;
+ * c > 16: compare chain, O(P) per value. */
+MI355_API int mi355_scan_in_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const int32_t *keys_host, unsigned P,
+                                int negate, const void *and_mask_dev, void *bitmap_dev, uint64_t *hits_dev);
+
 #define MI355_BITMAP_AND 0
 #define MI355_BITMAP_OR 1
 #define MI355_BITMAP_XOR 2

@@ -512,6 +512,40 @@ int mi355_scan_where_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, uns
     return launch(ctx, r);
 }
 
+int mi355_scan_in_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const int32_t *keys_host, unsigned P,
+                      int negate, const void *and_mask_dev, void *bitmap_dev, uint64_t *hits_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    if ((rc = check_width(c))) return rc;
+    if (P < 1 || P > (unsigned)kMaxKeys) return fail(MI355_E_INVALID, "P=%u outside 1..%u", P, kMaxKeys);
+    if (!keys_host) return fail(MI355_E_INVALID, "keys is null");
+    if (n == 0) {
+        if (hits_dev) HIP_TRY(hipMemsetAsync(hits_dev, 0, sizeof(uint64_t), ctx->stream));
+        return MI355_OK;
+    }
+    if (!packed_dev || !bitmap_dev) return fail(MI355_E_INVALID, "null device pointer");
+    if (((uintptr_t)packed_dev & 15) || ((uintptr_t)bitmap_dev & 15) || ((uintptr_t)and_mask_dev & 15))
+        return fail(MI355_E_INVALID, "packed_dev, bitmap_dev and and_mask_dev must be 16-byte aligned");
+    if ((rc = bind(ctx))) return rc;
+    std::vector<int32_t> padded((P + 7) / 8 * 8, keys_host[P - 1]);
+    memcpy(padded.data(), keys_host, P * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(ctx->keys_scratch, padded.data(), padded.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // `padded` dies at scope exit
+    LaunchReq r{};
+    r.op = kOpScanIn;
+    r.c = c;
+    r.scan.packed = (const uint8_t *)packed_dev;
+    r.scan.n = n;
+    r.scan.out = (uint8_t *)bitmap_dev;
+    r.scan.hits = (unsigned long long *)hits_dev;
+    r.scan.keys_dev = ctx->keys_scratch;
+    r.scan.nkeys = P;
+    r.scan.and_mask = (const uint8_t *)and_mask_dev;
+    r.scan.invert = negate ? 0xffffffffu : 0u;
+    return launch(ctx, r);
+}
+
 static int bitmap_launch(mi355_ctx *ctx, int op, const void *a, const void *b, void *out, uint64_t n, uint64_t *count_dev)
 {
     if (int brc = bind(ctx)) return brc;

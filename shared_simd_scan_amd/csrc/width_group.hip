@@ -108,6 +108,15 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         }
         break;
     }
+    case kOpScanIn: {
+        constexpr int VPL = scan_vpl(C, kModeEq);
+        using G = ScanGeom<C, VPL>;
+        static const int bpc = blocks_per_cu(in_kernel<C, 2, VPL>);
+        const uint64_t ntiles = (r.scan.n + G::TILE_VALUES - 1) / G::TILE_VALUES;
+        hipLaunchKernelGGL((in_kernel<C, 2, VPL>), dim3(grid_for(ntiles, scan_bpc(bpc, G::TILE_BYTES, r), r.num_cus)), dim3(kBlockThreads), 0,
+                           r.stream, r.scan);
+        break;
+    }
     case kOpDecompress: {
         static const int bpc = blocks_per_cu(decompress_kernel<C, 18>);
         const uint64_t ntiles = (r.decomp.n + DecompGeom<C>::TILE_VALUES - 1) / DecompGeom<C>::TILE_VALUES;

@@ -163,6 +163,20 @@ class ScanEngine:
                                          hits.data_ptr()))
         return bitmap, hits
 
+    def scan_in(self, keys: Sequence[int], col: PackedColumn, negate: bool = False,
+                and_mask: Optional[torch.Tensor] = None, bitmap: Optional[torch.Tensor] = None,
+                hits: Optional[torch.Tensor] = None):
+        """bitmap[i] = value_i in keys (NOT IN with negate=True) [& and_mask[i]]."""
+        k = np.ascontiguousarray(np.asarray(keys, dtype=np.int64).astype(np.int32))
+        if bitmap is None:
+            bitmap = self.alloc_bitmap(col.n)
+        if hits is None:
+            hits = torch.empty(1, dtype=torch.int64, device=self._dev)
+        check(lib().mi355_scan_in_dev(self._ctx, col.data.data_ptr(), col.n, col.c, k.ctypes.data, int(k.shape[0]),
+                                      1 if negate else 0, and_mask.data_ptr() if and_mask is not None else None,
+                                      bitmap.data_ptr(), hits.data_ptr()))
+        return bitmap, hits
+
     def bitmap_combine(self, op: str, a: torch.Tensor, b: torch.Tensor, n: int, out: Optional[torch.Tensor] = None):
         if out is None:
             out = self.alloc_bitmap(n)

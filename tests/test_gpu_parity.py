@@ -472,3 +472,83 @@ def test_scan_then_select_1e9(O, eng):
     for r in pick[:50]:
         assert int(O.gen_values("splitmix", 1, c, 42, first=int(r))[0]) == key
     assert int(eng.bitmap_count(bm, n).item()) == h
+
+
+def test_interleaved_launches_keep_scratch_clean(O, eng):
+    """the kernels share per-context scratch (hit-count replicas, tickets): interleave every kind of launch and check
+    each result -- a kernel that left the scratch dirty would corrupt the next one's counts"""
+    import torch
+
+    n, c = 5 * 8192 + 4321, 9
+    vals, col = make_column(O, eng, n, c, 31337)
+    packed_host = col.data.cpu().numpy()
+    v = vals.astype(np.int64)
+    keys8 = [int(x) for x in vals[:8]]
+    keys100 = [int(x) for x in vals[100:200]]
+    exp8 = O.shared_scan_eq(packed_host, n, c, keys8)[1]
+    exp100 = O.shared_scan_eq(packed_host, n, c, keys100)[1]
+    for rnd in range(6):
+        key = int(vals[rnd])
+        _, h = eng.scan(key, col)
+        assert int(h.item()) == int((v == key).sum())
+        _, h8 = eng.shared_scan(keys8, col, layout="linear" if rnd % 2 else "per_predicate")
+        assert np.array_equal(h8.cpu().numpy().astype(np.uint64), exp8)
+        bm, hr = eng.scan_range(10, 200, col)
+        assert int(hr.item()) == int(((v >= 10) & (v <= 200)).sum())
+        assert int(eng.bitmap_count(bm, n).item()) == int(hr.item())
+        _, h100 = eng.shared_scan(keys100, col, layout="per_predicate" if rnd % 2 else "linear")
+        assert np.array_equal(h100.cpu().numpy().astype(np.uint64), exp100)
+        _, hw = eng.scan_where("!=", key, col, and_mask=bm)
+        assert int(hw.item()) == int(((v != key) & (v >= 10) & (v <= 200)).sum())
+        ids, cnt = eng.bitmap_to_rowids(bm, n, capacity=16)
+        assert int(cnt.item()) == int(hr.item())
+    torch.cuda.synchronize()
+
+
+def test_two_contexts_two_streams(O):
+    """independent contexts on their own streams do not share scratch"""
+    import torch
+
+    from shared_simd_scan_amd import ScanEngine
+
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    e1, e2 = ScanEngine(0, stream=s1), ScanEngine(0, stream=s2)
+    n, c = 2_000_000, 9
+    with torch.cuda.stream(s1):
+        c1 = e1.generate("mod", n, c, 5)
+    with torch.cuda.stream(s2):
+        c2 = e2.generate("mod", n, c, 7)
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(20):
+        with torch.cuda.stream(s1):
+            outs.append(("a", e1.scan(3, c1)[1]))
+        with torch.cuda.stream(s2):
+            outs.append(("b", e2.scan(3, c2)[1]))
+    torch.cuda.synchronize()
+    for tag, h in outs:
+        assert int(h.item()) == (n // 5 if tag == "a" else (n - 3 + 6) // 7)
+
+
+@pytest.mark.parametrize("c,P", [(1, 1), (5, 7), (9, 1), (9, 40), (12, 300), (16, 1024), (17, 5), (21, 33), (32, 4)])
+def test_scan_in_list(O, eng, c, P):
+    n = 2 * 8192 + 1001
+    vals, col = make_column(O, eng, n, c, 7000 + c + P)
+    rng = np.random.default_rng(P * 31 + c)
+    keys = [int(vals[int(i)]) for i in rng.integers(0, n, size=P)]
+    if P > 3:
+        keys[1] = keys[0]
+        keys[2] = -5
+        if c < 31:
+            keys[3] = (1 << c) + 1
+    keys = [k if k < 2 ** 31 else k - 2 ** 32 for k in keys]
+    member = np.isin(vals.astype(np.int64), np.array([k for k in keys if 0 <= k < (1 << c)] +
+                                                     [k + 2 ** 32 for k in keys if k < 0 and c == 32], dtype=np.int64))
+    bm, hits = eng.scan_in(keys, col)
+    assert np.array_equal(bm.cpu().numpy(), np_bitmap(member)) and int(hits.item()) == int(member.sum())
+    bm, hits = eng.scan_in(keys, col, negate=True)
+    assert np.array_equal(bm.cpu().numpy(), np_bitmap(~member)) and int(hits.item()) == int((~member).sum())
+    prev, _ = eng.scan_where(">=", int(vals[7]), col)
+    bm, hits = eng.scan_in(keys, col, and_mask=prev)
+    expect = member & (vals.astype(np.int64) >= int(vals[7]))
+    assert np.array_equal(bm.cpu().numpy(), np_bitmap(expect)) and int(hits.item()) == int(expect.sum())
