@@ -231,8 +231,10 @@ def main():
         value = world * n / (elapsed / args.steps)
         achieved = algo_bytes / (dev_ms * 1e-3) / 1e9
         line = {
-            "metric": "scanned values/sec (equality scan, 9-bit packed column, bitmap + hit count out)"
-            if args.workload == "scan_eq" else f"{args.workload} values/sec",
+            # BASELINE.json: "scanned values/sec + achieved HBM GB/s, 1e9 x 9-bit column, 1/2/4/8 GPU";
+            # `value` is the values/sec half, `achieved_hbm_gb_per_s` (= roofline.achieved) the other
+            "metric": "scanned values/sec + achieved HBM GB/s, 1e9 x 9-bit column (equality scan, bitmap + hit count out)"
+            if args.workload == "scan_eq" and c == 9 and n == 1_000_000_000 else f"{args.workload} values/sec, {n:.0e} x {c}-bit column",
             "value": value, "unit": "values/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32" if args.workload != "decompress" else "i32", "data": "synthetic",
@@ -242,6 +244,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(args, kname),
                          "kernel": kname, "kernel_ms": dev_ms, "algorithmic_bytes": algo_bytes,
                          "read_gb_per_s": n * c / 8 / (dev_ms * 1e-3) / 1e9},
+            "achieved_hbm_gb_per_s": achieved * world,  # all ranks (weak scaling: every GPU streams its own shard)
             "hits": int(hits.sum().item()) if hits is not None else None,
         }
         if gather_ms is not None:
