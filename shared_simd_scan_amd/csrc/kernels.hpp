@@ -855,42 +855,8 @@ template <int C, int I> __device__ __forceinline__ uint32_t lut_lookup(const uin
     }
 }
 
-// Y[g] = (lo, hi): byte q of the pair = bitmap byte of key q for the lane's 8-value group g
-template <int C, int VPL, int G, bool TAIL, int NW>
-__device__ __forceinline__ void lut_groups(const uint32_t (&w)[NW], const uint8_t *table, int valid, uint32_t (&Y)[VPL / 8][2])
-{
-    uint32_t lo = 0, hi = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint32_t x;
-        // compile-time position: one template instantiation per value
-        if constexpr (true) {
-            constexpr int K = 8 * G;
-            switch (i) { // unrolled: i is a constant after unrolling
-            case 0: x = extract<C, K + 0, NW>(w); break;
-            case 1: x = extract<C, K + 1, NW>(w); break;
-            case 2: x = extract<C, K + 2, NW>(w); break;
-            case 3: x = extract<C, K + 3, NW>(w); break;
-            case 4: x = extract<C, K + 4, NW>(w); break;
-            case 5: x = extract<C, K + 5, NW>(w); break;
-            case 6: x = extract<C, K + 6, NW>(w); break;
-            default: x = extract<C, K + 7, NW>(w); break;
-            }
-        }
-        uint32_t m = lut_lookup<C, 0>(table, x);
-        if constexpr (TAIL) m = (8 * G + i < valid) ? m : 0u;
-        if (i < 4)
-            lo |= m << (8 * i);
-        else
-            hi |= m << (8 * (i - 4));
-    }
-    transpose8x8(lo, hi);
-    Y[G][0] = lo;
-    Y[G][1] = hi;
-    if constexpr (G + 1 < VPL / 8) lut_groups<C, VPL, G + 1, TAIL, NW>(w, table, valid, Y);
-}
-
-// the same from values extracted once per tile (multi-pass kernel: the passes only differ in the table)
+// Y[g] = (lo, hi): byte q of the pair = bitmap byte of key q for the lane's 8-value group g;
+// x[] = the lane's values, extracted once per tile (the passes of a multi-pass scan only differ in the table)
 template <int C, int VPL, bool TAIL>
 __device__ __forceinline__ void lut_groups_x(const uint32_t (&x)[VPL], const uint8_t *table, int valid, uint32_t (&Y)[VPL / 8][2])
 {
@@ -1042,8 +1008,8 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
         const uint64_t next = tile + stride;
         if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
         const bool full = tile < tc.nfull;
-        uint32_t xs[MULTI ? VPL : 1];
-        if constexpr (MULTI) extract_all<C, VPL, 0, G::LANE_DWORDS>(w, xs);
+        uint32_t xs[VPL];
+        extract_all<C, VPL, 0, G::LANE_DWORDS>(w, xs);
 
         if constexpr (MULTI && LAYOUT == 1) {
             // Linear layout, many keys: row g (8-value group) holds P bytes, and a lane's 8 rows are contiguous.
@@ -1088,10 +1054,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
             uint32_t Y[GROUPS][2];
             uint32_t out[8][WORDS];
             if (full) {
-                if constexpr (MULTI)
-                    lut_groups_x<C, VPL, false>(xs, table, VPL, Y);
-                else
-                    lut_groups<C, VPL, 0, false, G::LANE_DWORDS>(w, table, VPL, Y);
+                lut_groups_x<C, VPL, false>(xs, table, VPL, Y);
                 if (LAYOUT == 0 || a.hits) lut_gather_keys<VPL>(Y, out);
                 if (a.hits) {
 #pragma unroll
@@ -1127,10 +1090,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                 const int64_t left = (int64_t)(tc.n - tile * G::TILE_VALUES) - (int64_t)lane * VPL;
                 const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
                 const int nbytes = (valid + 7) / 8;
-                if constexpr (MULTI)
-                    lut_groups_x<C, VPL, true>(xs, table, valid, Y);
-                else
-                    lut_groups<C, VPL, 0, true, G::LANE_DWORDS>(w, table, valid, Y);
+                lut_groups_x<C, VPL, true>(xs, table, valid, Y);
                 lut_gather_keys<VPL>(Y, out);
                 uint32_t tcnt[8];
 #pragma unroll
