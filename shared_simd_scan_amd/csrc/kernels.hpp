@@ -916,6 +916,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
     __shared__ __attribute__((aligned(16))) uint8_t lut_static[MULTI ? 16 : L::TABLE_BYTES];
     uint8_t *const lut = MULTI ? mi355_dyn_lds : lut_static; // MULTI: npass * TABLE_BYTES dynamic bytes
     __shared__ uint32_t s_hits[MULTI ? kMaxKeys : 1];          // MULTI: per-block hit counters (block_hits_add8)
+    __shared__ __attribute__((aligned(16))) uint8_t stage[(LAYOUT == 1 && !MULTI) ? kWavesPerBlock : 1][(LAYOUT == 1 && !MULTI) ? GROUPS * 8 * 64 : 16];
     if constexpr (MULTI)
         for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxKeys; k += kBlockThreads) s_hits[k] = 0;
 
@@ -969,13 +970,19 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
             }
         } else {
             const uint64_t g0 = t * G::BITMAP_BYTES + (uint64_t)lane * GROUPS;
-            if (!MULTI && P == 8) { // the lane's GROUPS x 8 keys are 8*GROUPS contiguous bytes
-                u32x4 *dst = (u32x4 *)(a.out + g0 * 8);
+            if (!MULTI && P == 8) {
+                // the lane's GROUPS x 8 keys are 8*GROUPS contiguous bytes, the wave's tile 64 x that: transpose
+                // through a per-wave LDS stage so every store instruction writes 1 KiB contiguous instead of
+                // 64 x 16 B at a 64-B stride
+                u32x4 *st = (u32x4 *)stage[wave];
 #pragma unroll
                 for (int g = 0; g < GROUPS; g += 2) {
                     u32x4 v = {res[2 * g], res[2 * g + 1], res[2 * g + 2], res[2 * g + 3]};
-                    dst[g / 2] = v;
+                    st[lane * (GROUPS / 2) + g / 2] = v;
                 }
+                u32x4 *dst = (u32x4 *)(a.out + (t * G::BITMAP_BYTES) * 8);
+#pragma unroll
+                for (int j = 0; j < GROUPS / 2; j++) dst[j * 64 + lane] = st[j * 64 + lane];
             } else {
                 const uint32_t nk = (P - pass * 8) < 8 ? (P - pass * 8) : 8;
 #pragma unroll
