@@ -143,10 +143,8 @@ def main():
         key = 3
     else:
         col = eng.generate("splitmix", n, c, 42, first_row=first)
-        import numpy as np
-
-        from oracle import oracle  # key = v[12345] of the global column
-        key = int(oracle().gen_values("splitmix", 1, c, 42, first=12345)[0])
+        # key = v[12345] of the global column, read back through the engine itself
+        key = int(eng.decompress(eng.generate("splitmix", 1, c, 42, first_row=12345)).cpu()[0].item()) & mask
     nb = (n + 7) // 8
     keys8 = list(range(8))
 
