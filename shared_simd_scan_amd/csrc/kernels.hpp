@@ -10,6 +10,17 @@
 //       --v_cmp + v_addc_co_u32 (acc = 2*acc + match: one VALU op appends a result bit)-->
 //   one 32-bit bitmap word per 32 values in the lane, written back as 16 B / lane (1 KiB / wave).
 //
+// Kernels in this file:
+//   scan_kernel            equality / range scan (+ negation, + AND with an earlier bitmap), one bitmap
+//   shared_lut_kernel      shared multi-predicate scan through an LDS lookup table + 8x8 bit transposes
+//   shared_general_kernel  shared scan by compare chain, for key counts whose tables do not fit in LDS
+//   in_kernel              IN-list scan (one bitmap for a key set)
+//   decompress_kernel      packed -> int32, lane per value
+//   pack_kernel            packer and synthetic column generators
+//   bitmap_kernel, rowid_* bitmap combine / count, selection vector
+// ABL / DEPTH template knobs of scan_kernel exist for tools/tune_scan.hip (ablations, diagnostics, experiments);
+// the shipped dispatch (width_group.hip) always uses ABL = 0, DEPTH = 1.
+//
 // What this replaces in the reference (RRr89/Shared_SIMD_Scan): the pshufb byte-gather + pmulld /
 // psrld shift + pcmpeqd + movmskps chains of src/simd_scan.cpp:103-306, src/simd_scan_shared.cpp:34-151,
 // src/simd_scan_shared_linear.cpp:9-62 and src/simd_scan_decompression.cpp:237-470.  No MFMA: this is
