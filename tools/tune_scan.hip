@@ -85,7 +85,10 @@ int main(int argc, char **argv)
     const int column = argc > 3 ? atoi(argv[3]) : 0;
     const int REPS = argc > 4 ? atoi(argv[4]) : 15;
     const int NOHITS = argc > 5 ? atoi(argv[5]) : 0;
-    constexpr int C = 9;
+#ifndef TUNE_C
+#define TUNE_C 9
+#endif
+    constexpr int C = TUNE_C;
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
