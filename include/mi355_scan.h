@@ -70,6 +70,11 @@ MI355_API int mi355_ctx_create(int device, void *hip_stream /* hipStream_t or NU
 MI355_API int mi355_ctx_destroy(mi355_ctx *ctx);
 MI355_API int mi355_ctx_synchronize(mi355_ctx *ctx);
 MI355_API int mi355_device_count(int *count);
+/* re-point the context at another HIP stream (e.g. a capture stream: the *_dev scan / decompress / bitmap entry
+ * points enqueue work only -- no allocation, no synchronisation -- so they can be captured into a hipGraph;
+ * exceptions: mi355_shared_scan_eq_dev / mi355_scan_in_dev with P > 8 synchronise to upload the key list, and
+ * mi355_bitmap_to_rowids_dev may grow its workspace) */
+MI355_API int mi355_ctx_set_stream(mi355_ctx *ctx, void *hip_stream);
 /* tuning knobs: "max_blocks_per_cu" (0 = the engine's per-kernel default), "dma_aux" (bits 0-3: cache policy of
  * the HBM->LDS loads, 0 default / 2 non-temporal; bit 4: non-temporal output stores in decompress; default 18) */
 MI355_API int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value);
@@ -173,6 +178,11 @@ MI355_API int mi355_bitmap_count_dev(mi355_ctx *ctx, const void *bitmap_dev, uin
  * entries are written) and the total number of set bits into count_dev.  workspace: ctx-owned, grows on demand. */
 MI355_API int mi355_bitmap_to_rowids_dev(mi355_ctx *ctx, const void *bitmap_dev, uint64_t n, uint64_t first_row,
                                          uint64_t *rowids_dev, uint64_t capacity, uint64_t *count_dev);
+
+/* ---- row-range sharding helper (one process per GPU): rank's rows [first, first+count) of an n-row
+ * column split over `world` ranks at multiples of 8192 rows, so every shard's packed slice starts 16-byte aligned on
+ * a whole value and its bitmap slice on a whole byte.  Pure arithmetic, no device needed. */
+MI355_API int mi355_shard_rows(uint64_t n, unsigned world, unsigned rank, uint64_t *first, uint64_t *count);
 
 /* ---- introspection used by bench.py / tests --------------------------------------------------- */
 /* name of the HIP kernel a given op dispatches to at width c ("scan_eq", "scan_range", "shared_scan",

@@ -191,6 +191,27 @@ int mi355_ctx_synchronize(mi355_ctx *ctx)
     return MI355_OK;
 }
 
+int mi355_ctx_set_stream(mi355_ctx *ctx, void *hip_stream)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    ctx->stream = (hipStream_t)hip_stream;
+    return MI355_OK;
+}
+
+int mi355_shard_rows(uint64_t n, unsigned world, unsigned rank, uint64_t *first, uint64_t *count)
+{
+    if (!first || !count || world < 1 || rank >= world) return fail(MI355_E_INVALID, "bad shard arguments");
+    const uint64_t align = 8192;
+    uint64_t per = (n + world - 1) / world;
+    per = (per + align - 1) / align * align;
+    const uint64_t a = (uint64_t)rank * per < n ? (uint64_t)rank * per : n;
+    const uint64_t b = (uint64_t)(rank + 1) * per < n ? (uint64_t)(rank + 1) * per : n;
+    *first = a;
+    *count = b - a;
+    return MI355_OK;
+}
+
 int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value)
 {
     int rc = resolve(ctx);

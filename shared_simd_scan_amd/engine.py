@@ -81,6 +81,11 @@ class ScanEngine:
     def set_option(self, name: str, value: int) -> None:
         check(lib().mi355_ctx_set_option(self._ctx, name.encode(), int(value)))
 
+    def use_stream(self, stream: torch.cuda.Stream) -> None:
+        """enqueue subsequent work on `stream` (e.g. the capture stream inside torch.cuda.graph)"""
+        self.stream = stream
+        check(lib().mi355_ctx_set_stream(self._ctx, C.c_void_p(stream.cuda_stream)))
+
     def synchronize(self) -> None:
         check(lib().mi355_ctx_synchronize(self._ctx))
 

@@ -553,3 +553,33 @@ def test_scan_in_list(O, eng, c, P):
     bm, hits = eng.scan_in(keys, col, and_mask=prev)
     expect = member & (vals.astype(np.int64) >= int(vals[7]))
     assert np.array_equal(bm.cpu().numpy(), np_bitmap(expect)) and int(hits.item()) == int(expect.sum())
+
+
+def test_scan_can_be_captured_in_a_hip_graph(O, eng):
+    """the *_dev scan entry points only enqueue work (no allocation, no sync): capture one into a HIP graph on a
+    side stream and replay it"""
+    import torch
+
+    n, c = 3_000_000, 9
+    vals, col = make_column(O, eng, n, c, 2024)
+    bitmap = eng.alloc_bitmap(n)
+    hits = torch.zeros(1, dtype=torch.int64, device="cuda")
+    key = int(vals[5])
+    eng.scan(key, col, bitmap=bitmap, hits=hits)  # warm-up outside capture (module load)
+    torch.cuda.synchronize()
+    original = eng.stream
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng.use_stream(side)
+        with torch.cuda.graph(g, stream=side):
+            eng.use_stream(torch.cuda.current_stream())
+            eng.scan(key, col, bitmap=bitmap, hits=hits)
+    eng.use_stream(original)
+    bitmap.zero_()
+    hits.zero_()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    obm, ohits = O.scan_eq(col.data.cpu().numpy(), n, c, key)
+    assert np.array_equal(bitmap.cpu().numpy(), obm) and int(hits.item()) == ohits

@@ -105,3 +105,21 @@ def test_sharded_scan_world2_gloo(n):
         assert p.exitcode == 0
     status, ranges = q.get(timeout=10)
     assert status == "ok", ranges
+
+
+def test_c_abi_shard_rows_matches_python():
+    import ctypes as C
+
+    from shared_simd_scan_amd import lib
+    from shared_simd_scan_amd.sharded import shard_rows
+
+    L = lib()
+    for n in (0, 5, 8192, 100_003, 1_000_000_000, 8_000_000_000):
+        for world in (1, 2, 3, 8):
+            py = shard_rows(n, world)
+            for r in range(world):
+                a, cnt = C.c_uint64(), C.c_uint64()
+                assert L.mi355_shard_rows(n, world, r, C.byref(a), C.byref(cnt)) == 0
+                assert (a.value, a.value + cnt.value) == py[r]
+    a, cnt = C.c_uint64(), C.c_uint64()
+    assert L.mi355_shard_rows(10, 2, 2, C.byref(a), C.byref(cnt)) == -1
