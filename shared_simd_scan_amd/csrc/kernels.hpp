@@ -827,6 +827,8 @@ __global__ __launch_bounds__(kBlockThreads) void shared_general_kernel(ScanArgs 
 // Keys outside [0, 2^C) get no bit anywhere (they match nothing, as in the reference).  P <= 64 (8 passes).
 constexpr int kLutMaxPasses = kMaxKeys / 8; // as many as fit in LDS beside the tiles (checked by the launcher)
 
+struct __attribute__((packed, aligned(1))) Unaligned128 { uint32_t w[4]; };
+
 extern __shared__ uint8_t mi355_dyn_lds[]; // lookup tables of the multi-pass LUT kernel (size set at launch)
 
 template <int C> struct LutGeom {
@@ -1041,9 +1043,10 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                     uint32_t xg[8];
 #pragma unroll
                     for (int i = 0; i < 8; i++) xg[i] = xs[8 * g + i];
-                    for (uint32_t pass = 0; pass < npass; pass++) {
+                    auto pass8 = [&](uint32_t pass, uint32_t &lo, uint32_t &hi) {
                         const uint8_t *table = lut + pass * L::TABLE_BYTES;
-                        uint32_t lo = 0, hi = 0;
+                        lo = 0;
+                        hi = 0;
 #pragma unroll
                         for (int i = 0; i < 8; i++) {
                             const uint32_t m = lut_lookup<C, 0>(table, xg[i]);
@@ -1053,6 +1056,20 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                                 hi |= m << (8 * (i - 4));
                         }
                         transpose8x8(lo, hi);
+                    };
+                    uint32_t pass = 0;
+                    // two passes = 16 keys = one 16-byte store while whole pairs remain
+                    for (; pass + 2 <= P / 8; pass += 2) {
+                        uint32_t l0, h0, l1, h1;
+                        pass8(pass, l0, h0);
+                        pass8(pass + 1, l1, h1);
+                        Unaligned128 v;
+                        v.w[0] = l0; v.w[1] = h0; v.w[2] = l1; v.w[3] = h1;
+                        *(Unaligned128 *)(row + pass * 8) = v;
+                    }
+                    for (; pass < npass; pass++) {
+                        uint32_t lo, hi;
+                        pass8(pass, lo, hi);
                         const uint32_t nk = (P - pass * 8) < 8 ? (P - pass * 8) : 8;
                         if (nk == 8) {
                             store8_unaligned(row + pass * 8, lo, hi);
