@@ -53,6 +53,12 @@ inline bool get_bit(std::vector<uint8_t> const &vector, size_t absolute_index)
 {
     return (vector[absolute_index / 8] & (1 << (absolute_index % 8))) > 0;
 }
+// src/util.cpp:60-67: the uint32_t overload reads element absolute_index/8 and keeps only its low byte
+inline bool get_bit(std::vector<uint32_t> const &vector, size_t absolute_index)
+{
+    const uint8_t element = (uint8_t)vector[absolute_index / 8];
+    return (element & (1 << (absolute_index % 8))) > 0;
+}
 
 namespace mi355_dropin {
 inline void check(int rc, const char *what)
