@@ -98,7 +98,10 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 static const bool attr = ((void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 2, VPL, 0, true>,
                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - lut_static_lds<C, VPL>())), true);
                 (void)attr;
-                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, true>), dim3(grid_for(ntiles, lut_bpc(8), r.num_cus)),
+                // measured at P = 64, 1e9 x 9 bit: two blocks per CU 2.28 ms, one 2.59 (the passes are VALU-heavy: a
+                // second wave per SIMD fills the issue slots); the linear layout prefers one (3.00 against 3.36 ms)
+                const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : 2;
+                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, true>), dim3(grid_for(ntiles, want, r.num_cus)),
                                    dim3(kBlockThreads), dyn, r.stream, r.scan);
             }
         } else { // more keys than the tables hold: compare chain, ceil(P/8) passes over the registers
