@@ -195,3 +195,32 @@ def test_generators_match_reference_bench_inputs(O):
     a = O.gen_values("splitmix", n, 9, 42)
     b = O.gen_values("splitmix", 100, 9, 42, first=900)
     assert np.array_equal(a[900:], b) and a.max() < 512 and len(np.unique(a)) > 400
+
+
+def test_cfg1_reference_vs_oracle_1e7(O):
+    """BASELINE config 1 (n = 1e7, c = 9, v = i % 5, key 3; src/benchmark.cpp:173,:150): when the reference itself is
+    available (oracle/_ref, built from /root/reference by oracle/Makefile) run its AVX2 and scalar scans and hold the
+    oracle against them on the full column; hits must be 2,000,000."""
+    from oracle import RefLib, ref_available
+
+    if not ref_available(9):
+        pytest.skip("oracle/_ref/libref_w9.so not built (needs /root/reference)")
+    R = RefLib(9)
+    n, c = 10_000_000, 9
+    vals = O.gen_values("mod", n, c, 5)
+    packed = O.pack(vals, c)
+    assert np.array_equal(packed, R.compress(vals.astype(np.uint16)))
+    obm, ohits = O.scan_eq(packed, n, c, 3)
+    assert ohits == 2_000_000
+    for variant in ("scan_256_unrolled", "scan_256", "scan_128_unrolled", "scan_128", "scan_unvectorized"):
+        rbuf, rhits = R.scan(variant, 3, packed, n)
+        assert rhits == 2_000_000, variant
+        assert np.array_equal(rbuf[: n // 8], obm), variant  # n is a multiple of 32: whole-buffer equality
+    dec = R.decompress("decompress_256_avx2", packed, n)[:n]
+    assert np.array_equal(dec, O.decompress(packed, n, c))
+    keys = list(range(8))
+    vals8 = O.gen_values("mod", n, c, 8)
+    packed8 = O.pack(vals8, c)
+    ref = R.shared_scan("shared_scan_128_standard", keys, packed8, n)
+    mine, hits = O.shared_scan_eq(packed8, n, c, keys)
+    assert np.array_equal(ref[:, : n // 8], mine) and hits.tolist() == [n // 8] * 8
