@@ -25,6 +25,7 @@ struct mi355_ctx {
     hipStream_t stream = nullptr;
     int num_cus = 256;
     int max_blocks_per_cu = 0;
+    int scan_nt_stores = -1; // -1: by bitmap size (see width_group.hip), 0 plain, 1 non-temporal
     int dma_aux = 18; // bits 0-3: policy of the HBM->LDS loads (2 = non-temporal: the column is streamed once);
                       // bit 4: non-temporal stores in decompress
     unsigned long long *hits_scratch = nullptr; // host-pointer API: where the kernels deliver hit counts
@@ -99,6 +100,7 @@ int launch(mi355_ctx *ctx, LaunchReq &r)
     r.num_cus = ctx->num_cus;
     r.max_blocks_per_cu = ctx->max_blocks_per_cu;
     r.dma_aux = ctx->dma_aux;
+    r.scan_nt_stores = ctx->scan_nt_stores;
     r.scan.scratch = ctx->kernel_scratch;
     hipError_t e = kGroups[(r.c - 1) / 4](r);
     if (e != hipSuccess) return fail(MI355_E_HIP, "kernel launch (op %d, c=%u): %s", r.op, r.c, hipGetErrorString(e));
@@ -221,6 +223,8 @@ int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value)
         ctx->max_blocks_per_cu = value;
     else if (!strcmp(name, "dma_aux"))
         ctx->dma_aux = value;
+    else if (!strcmp(name, "scan_nt_stores"))
+        ctx->scan_nt_stores = value;
     else
         return fail(MI355_E_INVALID, "unknown option %s", name);
     return MI355_OK;

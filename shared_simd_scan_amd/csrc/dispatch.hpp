@@ -17,6 +17,7 @@ struct LaunchReq {
     int num_cus;
     int max_blocks_per_cu; // 0 = what the occupancy query allows
     int dma_aux;           // cache policy of the HBM->LDS loads: 0 default, 2 nt
+    int scan_nt_stores;    // bitmap stores of the eq / range scan: -1 by size, 0 plain, 1 non-temporal
     ScanArgs scan;
     DecompArgs decomp;
 };

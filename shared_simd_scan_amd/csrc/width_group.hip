@@ -52,9 +52,15 @@ template <int C, int MODE> void launch_scan(const LaunchReq &r)
     static const int bpc = blocks_per_cu(scan_kernel<C, MODE, 2, VPL>);
     const uint64_t ntiles = (r.scan.n + G::TILE_VALUES - 1) / G::TILE_VALUES;
     const unsigned grid = grid_for(ntiles, scan_bpc(bpc, G::TILE_BYTES, r), r.num_cus);
-    // dma_aux: cache policy of the HBM->LDS stream; 2 (non-temporal: the column is read once) is the default
+    // dma_aux: cache policy of the HBM->LDS stream; 2 (non-temporal: the column is read once) is the default.
+    // Bitmap stores: plain while the bitmap (n/8 bytes) roughly fits in the 256 MiB Infinity Cache, non-temporal beyond
+    // (measured, tools/sweep.py --nts 0,1 at c = 9: 1e9 rows plain 0.196 ms / nt 0.205; 2e9 0.400 / 0.420; 3e9 0.672 /
+    // 0.650; 6e9 1.318 / 1.264)
+    const bool nt_stores = r.scan_nt_stores < 0 ? r.scan.n / 8 > (300ull << 20) : r.scan_nt_stores != 0;
     if (r.dma_aux == 0)
         hipLaunchKernelGGL((scan_kernel<C, MODE, 0, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
+    else if (nt_stores)
+        hipLaunchKernelGGL((scan_kernel<C, MODE, 18, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
     else
         hipLaunchKernelGGL((scan_kernel<C, MODE, 2, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
 }

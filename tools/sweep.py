@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--ops", default="scan_eq,scan_range,shared_scan,decompress")
     ap.add_argument("--reps", type=int, default=12)
     ap.add_argument("--aux", default="2")
+    ap.add_argument("--nts", default="-1", help="scan_nt_stores values to sweep (-1 auto, 0 plain, 1 nt)")
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
     import torch
@@ -47,8 +48,9 @@ def main():
             fn, nbytes = steps[op]
             for aux in [int(x) for x in args.aux.split(",")]:
                 eng.set_option("dma_aux", aux)
-                for bpc in [int(x) for x in args.bpc.split(",")]:
+                for bpc, nts in [(int(x), int(y)) for x in args.bpc.split(",") for y in args.nts.split(",")]:
                     eng.set_option("max_blocks_per_cu", bpc)
+                    eng.set_option("scan_nt_stores", nts)
                     for _ in range(3):
                         fn()
                     torch.cuda.synchronize()
@@ -62,10 +64,10 @@ def main():
                         ms.append(e0.elapsed_time(e1))
                     ms.sort()
                     med, mn = ms[len(ms) // 2], ms[0]
-                    row = {"op": op, "bits": c, "aux": aux, "bpc": bpc, "med_ms": med, "min_ms": mn,
+                    row = {"op": op, "bits": c, "aux": aux, "bpc": bpc, "nts": nts, "med_ms": med, "min_ms": mn,
                            "gbs_med": nbytes / med / 1e6, "gbs_min": nbytes / mn / 1e6, "values_per_s": n / med * 1e3}
                     rows.append(row)
-                    print(f"{op:12s} c={c:2d} aux={aux} bpc={bpc}  med {med:8.4f} ms  min {mn:8.4f} ms  "
+                    print(f"{op:12s} c={c:2d} aux={aux} bpc={bpc} nts={nts:2d}  med {med:8.4f} ms  min {mn:8.4f} ms  "
                           f"{row['gbs_med']:7.1f} GB/s  {row['values_per_s']:.3e} values/s", flush=True)
         del col, bitmap, out8, dec
         torch.cuda.empty_cache()
