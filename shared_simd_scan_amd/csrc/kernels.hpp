@@ -924,6 +924,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
     constexpr int WORDS = G::WORDS;
     constexpr int GROUPS = VPL / 8;
     constexpr int AUX = AUX_ & 15;
+    constexpr int NTS = (AUX_ & 16) ? 1 : 0; // non-temporal result stores (outputs larger than the Infinity Cache)
     constexpr int NRES = LAYOUT == 0 ? 8 * WORDS : GROUPS * 2; // result dwords per lane, tile and pass
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t lut_static[MULTI ? 16 : L::TABLE_BYTES];
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                     uint32_t v[WORDS];
 #pragma unroll
                     for (int j = 0; j < WORDS; j++) v[j] = res[q * WORDS + j];
-                    store_words<WORDS>(dst, v);
+                    store_words<WORDS, NTS>(dst, v);
                 }
                 dst += a.out_stride;
             }
@@ -995,7 +996,12 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                 }
                 u32x4 *dst = (u32x4 *)(a.out + (t * G::BITMAP_BYTES) * 8);
 #pragma unroll
-                for (int j = 0; j < GROUPS / 2; j++) dst[j * 64 + lane] = st[j * 64 + lane];
+                for (int j = 0; j < GROUPS / 2; j++) {
+                    if constexpr (NTS)
+                        __builtin_nontemporal_store(st[j * 64 + lane], dst + j * 64 + lane);
+                    else
+                        dst[j * 64 + lane] = st[j * 64 + lane];
+                }
             } else {
                 const uint32_t nk = (P - pass * 8) < 8 ? (P - pass * 8) : 8;
 #pragma unroll

@@ -82,16 +82,22 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
             const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : (G::TILE_BYTES < 4096 ? 2 : 1);
             return want < occ ? want : occ;
         };
+        // result stores: non-temporal unless the P bitmaps together are small.  Measured (tools/sweep.py --nts 0,1, P = 8,
+        // c = 9): 1e8 rows (100 MB of bitmaps) 0.0540 -> 0.0525 ms, 5e8 0.220 -> 0.214, 1e9 0.409 -> 0.372; c = 17: -1..-4 %.
+        // Unlike the single bitmap of launch_scan, these outputs gain nothing from staying in the Infinity Cache.
+        const bool nt_stores = r.scan_nt_stores < 0 ? (r.scan.n / 8) * P > (64ull << 20) : r.scan_nt_stores != 0;
         if (P <= 8) { // LDS lookup table, one pass, deferred stores
-            if (linear) {
-                static const int bpc = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 1, false>);
-                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, false>), dim3(grid_for(ntiles, lut_bpc(bpc), r.num_cus)),
-                                   dim3(kBlockThreads), 0, r.stream, r.scan);
-            } else {
-                static const int bpc = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 0, false>);
-                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, false>), dim3(grid_for(ntiles, lut_bpc(bpc), r.num_cus)),
-                                   dim3(kBlockThreads), 0, r.stream, r.scan);
-            }
+            static const int bpc_lin = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 1, false>);
+            static const int bpc_pp = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 0, false>);
+            const dim3 grid(grid_for(ntiles, lut_bpc(linear ? bpc_lin : bpc_pp), r.num_cus));
+            if (linear && nt_stores)
+                hipLaunchKernelGGL((shared_lut_kernel<C, 18, VPL, 1, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+            else if (linear)
+                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+            else if (nt_stores)
+                hipLaunchKernelGGL((shared_lut_kernel<C, 18, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+            else
+                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
         } else if (lut_fits<C, VPL>(P)) { // one lookup table per pass of 8 keys, in dynamic LDS
             const size_t dyn = (size_t)((P + 7) / 8) * LutGeom<C>::TABLE_BYTES;
             if (linear) {
@@ -102,13 +108,19 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                                    dim3(kBlockThreads), dyn, r.stream, r.scan);
             } else {
                 static const bool attr = ((void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 2, VPL, 0, true>,
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - lut_static_lds<C, VPL>())),
+                                          (void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 18, VPL, 0, true>,
                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - lut_static_lds<C, VPL>())), true);
                 (void)attr;
                 // measured at P = 64, 1e9 x 9 bit: two blocks per CU 2.28 ms, one 2.59 (the passes are VALU-heavy: a
                 // second wave per SIMD fills the issue slots); the linear layout prefers one (3.00 against 3.36 ms)
                 const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : 2;
-                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, true>), dim3(grid_for(ntiles, want, r.num_cus)),
-                                   dim3(kBlockThreads), dyn, r.stream, r.scan);
+                if (nt_stores)
+                    hipLaunchKernelGGL((shared_lut_kernel<C, 18, VPL, 0, true>), dim3(grid_for(ntiles, want, r.num_cus)),
+                                       dim3(kBlockThreads), dyn, r.stream, r.scan);
+                else
+                    hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, true>), dim3(grid_for(ntiles, want, r.num_cus)),
+                                       dim3(kBlockThreads), dyn, r.stream, r.scan);
             }
         } else { // more keys than the tables hold: compare chain, ceil(P/8) passes over the registers
             static const int bpc = blocks_per_cu(shared_general_kernel<C, 2, VPL>);
@@ -129,7 +141,8 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
     case kOpDecompress: {
         static const int bpc = blocks_per_cu(decompress_kernel<C, 18>);
         const uint64_t ntiles = (r.decomp.n + DecompGeom<C>::TILE_VALUES - 1) / DecompGeom<C>::TILE_VALUES;
-        const unsigned grid = grid_for(ntiles, cap_bpc(bpc, r), r.num_cus);
+        // measured (tools/sweep.py, tools/ceilings.hip; 1e9 rows, c = 8..21): one block per CU is 2-4 % faster than 2..8
+        const unsigned grid = grid_for(ntiles, r.max_blocks_per_cu > 0 ? cap_bpc(bpc, r) : 1, r.num_cus);
         if (r.dma_aux == 0)
             hipLaunchKernelGGL((decompress_kernel<C, 0>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);
         else if (r.dma_aux == 2) // nt DMA loads only (tools/sweep.py --aux 2)

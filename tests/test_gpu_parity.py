@@ -249,6 +249,39 @@ def test_shared_scan_predicate_counts(O, eng, P, layout):
     assert np.array_equal(hits.cpu().numpy().astype(np.uint64), ohits)
 
 
+@pytest.mark.parametrize("nts", [0, 1])
+@pytest.mark.parametrize("c", [7, 9, 16, 21])
+def test_store_policy_variants_agree(O, eng, c, nts):
+    """the launcher picks plain or non-temporal result stores by output size (option scan_nt_stores: -1 auto);
+    both code paths are forced here on the same ragged column: eq, range, shared P = 3 / 8 / 24 in both layouts"""
+    n = 5 * 8192 + 4099
+    vals, col = make_column(O, eng, n, c, 4242 + c)
+    packed_host = col.data.cpu().numpy()
+    nb = (n + 7) // 8
+    eng.set_option("scan_nt_stores", nts)
+    try:
+        key = int(vals[99])
+        bm, hits = eng.scan(key, col)
+        obm, ohits = O.scan_eq(packed_host, n, c, key)
+        assert np.array_equal(bm.cpu().numpy(), obm) and int(hits.item()) == ohits
+        lo, hi = (1 << c) // 3, (1 << c) // 2
+        bm, hits = eng.scan_range(lo, hi, col)
+        obm, ohits = O.scan_range(packed_host, n, c, lo, hi)
+        assert np.array_equal(bm.cpu().numpy(), obm) and int(hits.item()) == ohits
+        for P in (3, 8, 24):
+            keys = [int(vals[(131 * k + 7) % n]) for k in range(P)]
+            for layout in ("per_predicate", "linear"):
+                out, hits = eng.shared_scan(keys, col, layout=layout)
+                oout, ohits = O.shared_scan_eq(packed_host, n, c, keys, layout)
+                got = out.cpu().numpy()
+                if layout == "per_predicate":
+                    got = got[:, :nb]
+                assert np.array_equal(got, oout), (c, nts, P, layout)
+                assert np.array_equal(hits.cpu().numpy().astype(np.uint64), ohits)
+    finally:
+        eng.set_option("scan_nt_stores", -1)
+
+
 @pytest.mark.parametrize("c,P", [(5, 40), (10, 520), (12, 200), (17, 129), (25, 72), (32, 16), (32, 600)])
 @pytest.mark.parametrize("layout", ["per_predicate", "linear"])
 def test_shared_scan_wide_and_many_keys(O, eng, c, P, layout):
