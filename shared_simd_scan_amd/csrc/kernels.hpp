@@ -821,21 +821,32 @@ __global__ __launch_bounds__(kBlockThreads) void shared_general_kernel(ScanArgs 
 // values give eight bytes = an 8x8 bit matrix (value x key); an in-register 8x8 bit transpose (3 masked
 // shift/xor rounds on a dword pair) turns it into the eight bitmap bytes (key x value).  That is ~1.1
 // cycles per (value, key) result instead of 8.2.
-//   C <= 10 : one table of 2^C entries per pass.
-//   C  > 10 : ceil(C/8) digit tables of 256 entries; entry_d[digit_d(v)] has bit q set iff digit_d(key[q]) ==
-//             digit_d(v); the AND over the digits is exact equality.
+//   one table of 2^C entries per pass while that is affordable: C <= 16 for a single pass (P <= 8: 64 KiB at most, one
+//             ds_read_u8 per value), C <= 10 for the multi-pass kernel (the tables of all passes share the LDS);
+//   else      ND digit tables (single pass: 2 digits for C <= 24, 3 beyond; multi-pass: byte digits);
+//             entry_d[digit_d(v)] has bit q set iff digit_d(key[q]) == digit_d(v); the AND over the digits is exact
+//             equality.
+// The block zeroes its tables and scatters the keys into them with LDS atomic ORs (O(table/4 + P) per block).
 // Keys outside [0, 2^C) get no bit anywhere (they match nothing, as in the reference).  P <= 64 (8 passes).
 constexpr int kLutMaxPasses = kMaxKeys / 8; // as many as fit in LDS beside the tiles (checked by the launcher)
 
 struct __attribute__((packed, aligned(1))) Unaligned128 { uint32_t w[4]; };
 
-extern __shared__ uint8_t mi355_dyn_lds[]; // lookup tables of the multi-pass LUT kernel (size set at launch)
+extern __shared__ __attribute__((aligned(16))) uint8_t mi355_dyn_lds[]; // lookup tables of the multi-pass LUT kernel (size set at launch)
 
-template <int C> struct LutGeom {
-    static constexpr bool SINGLE = C <= 10;
-    static constexpr int ND = SINGLE ? 1 : (C + 7) / 8;
-    static constexpr int ENTRIES = SINGLE ? (1 << C) : 256;
+template <int C, bool MULTI> struct LutGeom {
+    // digits per value: single pass 1 / 2 / 3 for C <= 16 / 24 / 32 (tables of <= 64 KiB, 2 x 4 KiB, 3 x 2 KiB);
+    // multi-pass 1 for C <= 10, else byte digits (small tables, so that many passes fit in LDS)
+    static constexpr int ND = MULTI ? (C <= 10 ? 1 : (C + 7) / 8) : (C <= 16 ? 1 : (C <= 24 ? 2 : 3));
+    static constexpr bool SINGLE = ND == 1;
+    static constexpr int DIGIT_BITS = SINGLE ? C : (MULTI ? 8 : (C + ND - 1) / ND);
+    static constexpr int ENTRIES = 1 << DIGIT_BITS;
     static constexpr int TABLE_BYTES = ND * ENTRIES; // per pass of 8 keys
+    // digit d of a value or key below 2^C
+    static __device__ __forceinline__ uint32_t digit(uint32_t x, int d)
+    {
+        return (d == ND - 1) ? (x >> (DIGIT_BITS * d)) : ((x >> (DIGIT_BITS * d)) & (uint32_t)(ENTRIES - 1));
+    }
 };
 
 // 8x8 bit transpose of the 64-bit matrix (hi:lo): bit (8r + c) <-> bit (8c + r)
@@ -852,25 +863,22 @@ __device__ __forceinline__ void transpose8x8(uint32_t &lo, uint32_t &hi)
     hi ^= t >> 4;
 }
 
-template <int C, int I> __device__ __forceinline__ uint32_t lut_lookup(const uint8_t *table, uint32_t x)
+template <int C, bool MULTI> __device__ __forceinline__ uint32_t lut_lookup(const uint8_t *table, uint32_t x)
 {
-    using L = LutGeom<C>;
+    using L = LutGeom<C, MULTI>;
     if constexpr (L::SINGLE) {
         return table[x];
     } else {
-        uint32_t m = table[x & 255u];
+        uint32_t m = table[L::digit(x, 0)];
 #pragma unroll
-        for (int d = 1; d < L::ND; d++) {
-            const uint32_t digit = (d == L::ND - 1) ? (x >> (8 * d)) : ((x >> (8 * d)) & 255u);
-            m &= table[d * 256 + digit];
-        }
+        for (int d = 1; d < L::ND; d++) m &= table[d * L::ENTRIES + L::digit(x, d)];
         return m;
     }
 }
 
 // Y[g] = (lo, hi): byte q of the pair = bitmap byte of key q for the lane's 8-value group g;
 // x[] = the lane's values, extracted once per tile (the passes of a multi-pass scan only differ in the table)
-template <int C, int VPL, bool TAIL>
+template <int C, int VPL, bool TAIL, bool MULTI>
 __device__ __forceinline__ void lut_groups_x(const uint32_t (&x)[VPL], const uint8_t *table, int valid, uint32_t (&Y)[VPL / 8][2])
 {
 #pragma unroll
@@ -878,7 +886,7 @@ __device__ __forceinline__ void lut_groups_x(const uint32_t (&x)[VPL], const uin
         uint32_t lo = 0, hi = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            uint32_t m = lut_lookup<C, 0>(table, x[8 * g + i]);
+            uint32_t m = lut_lookup<C, MULTI>(table, x[8 * g + i]);
             if constexpr (TAIL) m = (8 * g + i < valid) ? m : 0u;
             if (i < 4)
                 lo |= m << (8 * i);
@@ -920,14 +928,14 @@ template <int C, int AUX_, int VPL, int LAYOUT, bool MULTI>
 __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
 {
     using G = ScanGeom<C, VPL>;
-    using L = LutGeom<C>;
+    using L = LutGeom<C, MULTI>;
     constexpr int WORDS = G::WORDS;
     constexpr int GROUPS = VPL / 8;
     constexpr int AUX = AUX_ & 15;
     constexpr int NTS = (AUX_ & 16) ? 1 : 0; // non-temporal result stores (outputs larger than the Infinity Cache)
     constexpr int NRES = LAYOUT == 0 ? 8 * WORDS : GROUPS * 2; // result dwords per lane, tile and pass
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
-    __shared__ __attribute__((aligned(16))) uint8_t lut_static[MULTI ? 16 : L::TABLE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lut_static[(MULTI || L::TABLE_BYTES < 16) ? 16 : L::TABLE_BYTES];
     uint8_t *const lut = MULTI ? mi355_dyn_lds : lut_static; // MULTI: npass * TABLE_BYTES dynamic bytes
     __shared__ uint32_t s_hits[MULTI ? kMaxKeys : 1];          // MULTI: per-block hit counters (block_hits_add8)
     __shared__ __attribute__((aligned(16))) uint8_t stage[(LAYOUT == 1 && !MULTI) ? kWavesPerBlock : 1][(LAYOUT == 1 && !MULTI) ? GROUPS * 8 * 64 : 16];
@@ -946,21 +954,33 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
     // the tile's DMA does not depend on the tables: get it going first
     if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
 
-    for (uint32_t i = threadIdx.x; i < npass * L::TABLE_BYTES; i += kBlockThreads) {
-        const uint32_t pass = i / L::TABLE_BYTES, r = i % L::TABLE_BYTES;
-        const uint32_t digit = r / L::ENTRIES, e = r % L::ENTRIES;
-        uint32_t byte = 0;
+    // tables: zero, then OR bit (k % 8) into the entry (or, digit tables: the ND entries) of every in-range key k
+    {
+        uint32_t *const lut32 = (uint32_t *)lut;
+        const uint32_t ndw = (npass * L::TABLE_BYTES + 3) / 4;
+        for (uint32_t i = threadIdx.x; i < ndw; i += kBlockThreads) lut32[i] = 0;
+        __syncthreads();
+        auto scatter = [&](uint32_t k, uint32_t key) {
+            const bool in_range = C == 32 || (key >> (C & 31)) == 0;
+            if (!in_range) return;
+            const uint32_t base = (k >> 3) * L::TABLE_BYTES;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const uint32_t k = pass * 8 + q;
-            if (k < P) {
-                const uint32_t key = MULTI ? (uint32_t)a.keys_dev[k] : a.key[q];
-                const bool in_range = C == 32 || (key >> (C & 31)) == 0;
-                const uint32_t d = L::SINGLE ? key : ((key >> (8 * digit)) & 255u);
-                if (in_range && d == e) byte |= 1u << q;
+            for (int d = 0; d < L::ND; d++) {
+                const uint32_t e = L::SINGLE ? key : L::digit(key, d);
+                const uint32_t idx = base + d * L::ENTRIES + e;
+                __hip_atomic_fetch_or(lut32 + (idx >> 2), (1u << (k & 7)) << (8 * (idx & 3)), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        if constexpr (MULTI) {
+            for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) scatter(k, (uint32_t)a.keys_dev[k]);
+        } else {
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if ((uint32_t)q < P) scatter(q, a.key[q]);
             }
         }
-        lut[i] = (uint8_t)byte;
     }
     __syncthreads();
 
@@ -1055,7 +1075,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                         hi = 0;
 #pragma unroll
                         for (int i = 0; i < 8; i++) {
-                            const uint32_t m = lut_lookup<C, 0>(table, xg[i]);
+                            const uint32_t m = lut_lookup<C, MULTI>(table, xg[i]);
                             if (i < 4)
                                 lo |= m << (8 * i);
                             else
@@ -1095,7 +1115,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
             uint32_t Y[GROUPS][2];
             uint32_t out[8][WORDS];
             if (full) {
-                lut_groups_x<C, VPL, false>(xs, table, VPL, Y);
+                lut_groups_x<C, VPL, false, MULTI>(xs, table, VPL, Y);
                 if (LAYOUT == 0 || a.hits) lut_gather_keys<VPL>(Y, out);
                 if (a.hits) {
 #pragma unroll
@@ -1131,7 +1151,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                 const int64_t left = (int64_t)(tc.n - tile * G::TILE_VALUES) - (int64_t)lane * VPL;
                 const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
                 const int nbytes = (valid + 7) / 8;
-                lut_groups_x<C, VPL, true>(xs, table, valid, Y);
+                lut_groups_x<C, VPL, true, MULTI>(xs, table, valid, Y);
                 lut_gather_keys<VPL>(Y, out);
                 uint32_t tcnt[8];
 #pragma unroll

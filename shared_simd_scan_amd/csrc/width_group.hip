@@ -41,7 +41,7 @@ template <int C, int VPL> constexpr size_t lut_static_lds() { return 4 * ScanGeo
 // the multi-pass LUT kernel needs ceil(P/8) tables next to that in the CU's 160 KiB of LDS
 template <int C, int VPL> bool lut_fits(uint32_t P)
 {
-    const size_t tables = (size_t)((P + 7) / 8) * LutGeom<C>::TABLE_BYTES;
+    const size_t tables = ((size_t)((P + 7) / 8) * LutGeom<C, true>::TABLE_BYTES + 15) / 16 * 16;
     return tables + lut_static_lds<C, VPL>() <= 160 * 1024;
 }
 
@@ -99,7 +99,7 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
             else
                 hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
         } else if (lut_fits<C, VPL>(P)) { // one lookup table per pass of 8 keys, in dynamic LDS
-            const size_t dyn = (size_t)((P + 7) / 8) * LutGeom<C>::TABLE_BYTES;
+            const size_t dyn = ((size_t)((P + 7) / 8) * LutGeom<C, true>::TABLE_BYTES + 15) / 16 * 16;
             if (linear) {
                 static const bool attr = ((void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 2, VPL, 1, true>,
                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - lut_static_lds<C, VPL>())), true);
