@@ -70,6 +70,12 @@ enum ScanMode { kModeEq = 0, kModeRange = 1, kModeShared = 2 };
 template <int C, int VPL, int MODE> constexpr int scan_occ()
 {
     constexpr int lds = ScanGeom<C, VPL>::OCC;
+    if (MODE != 2 && C <= 7) {
+        // table-lookup decode (narrow_k): many lookups in flight, the predicate table (<= 16 KiB) sits next to the
+        // tiles, and the launcher runs 1-2 blocks per CU anyway
+        const int with_table = (160 * 1024) / (4 * ScanGeom<C, VPL>::LDS_BYTES + (1 << (2 * C)) + 64);
+        return with_table > 4 ? 4 : (with_table < 1 ? 1 : with_table);
+    }
     return MODE == 2 ? (lds > 4 ? 4 : lds) : lds;
 }
 
@@ -463,6 +469,34 @@ __device__ __forceinline__ void block_hits_flush(const ScanArgs &a, uint32_t *s_
     }
 }
 
+// ---- narrow widths: several values per LDS lookup -------------------------------------------------
+// Extract + v_cmp + v_addc costs 12-17 SIMD-cycles per value (all three are half-rate ops on gfx950), more than the
+// HBM stream leaves per value below ~8 bits (1e9 x 5 bit: 17 cycles per wave-value at 6 TB/s).  For C <= 7 the
+// eq / range scans therefore evaluate LK values per step through a table in LDS: index = the LK*C packed bits of LK
+// consecutive values (one v_bfe_u32 / v_alignbit_b32), entry = their LK predicate bits, appended to the bitmap word
+// with one v_lshl_or_b32 -- ~9 cycles per LK values.  The block builds the 2^(LK*C)-entry table from the predicate
+// (<= 16 KiB at C = 7) while its first tile's DMA is in flight.
+template <int C> constexpr int narrow_k() { return C == 1 ? 8 : (C <= 3 ? 4 : (C <= 7 ? 2 : 0)); }
+
+template <int C, int K, int NW> __device__ __forceinline__ uint32_t extract(const uint32_t (&w)[NW]);
+template <int C, int VPL, int K, int NW> __device__ __forceinline__ void extract_all(const uint32_t (&w)[NW], uint32_t (&x)[VPL]);
+
+template <int C, int VPL, int LK, int NW>
+__device__ __forceinline__ void decode_words_narrow(const uint32_t (&w)[NW], uint32_t (&res)[1][VPL / 32], const uint8_t *table)
+{
+    constexpr int NG = VPL / LK;  // lookups per lane and tile
+    constexpr int GPW = 32 / LK;  // lookups per bitmap word
+    uint32_t xs[NG];
+    extract_all<C * LK, NG, 0, NW>(w, xs);
+#pragma unroll
+    for (int j = 0; j < VPL / 32; j++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int g = GPW - 1; g >= 0; g--) acc = (acc << LK) | table[xs[j * GPW + g]];
+        res[0][j] = acc;
+    }
+}
+
 // ---- the scan kernel ------------------------------------------------------------------------
 // Per wave, per tile:  wait for the tile's DMA -> ds_read the lane's run into VGPRs -> (LDS is free)
 // store the PREVIOUS tile's bitmap words, then issue the NEXT tile's DMA -> decode/compare in registers.
@@ -524,6 +558,8 @@ __global__ __launch_bounds__(kBlockThreads, (DEPTH == 1 ? scan_occ<C, VPL, MODE>
     constexpr int NTS = (AUX_ & 32) ? 2 : ((AUX_ & 16) ? 1 : 0);
     static_assert(DEPTH == 1 || DEPTH == 2, "DEPTH");
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][DEPTH][G::LDS_BYTES];
+    constexpr int LK = (MODE != kModeShared && ABL == 0) ? narrow_k<C>() : 0; // values per table lookup (0: compare chain)
+    __shared__ __attribute__((aligned(16))) uint8_t nlut[LK ? (1 << (LK * C)) : 16];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -565,6 +601,21 @@ __global__ __launch_bounds__(kBlockThreads, (DEPTH == 1 ? scan_occ<C, VPL, MODE>
     if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
     if constexpr (DEPTH == 2) {
         if (tile + stride < tc.ntiles) tc.template issue<AUX>(a.packed, tile + stride, lds_wave + G::LDS_BYTES, lane);
+    }
+    if constexpr (LK > 0) {
+        // predicate table: bit j of entry e = predicate(field j of e); the same formulas as push1/2/4
+        constexpr uint32_t fmask = (1u << C) - 1u;
+        for (uint32_t e = threadIdx.x; e < (1u << (LK * C)); e += kBlockThreads) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < LK; j++) {
+                const uint32_t f = (e >> (j * C)) & fmask;
+                const bool hit = (MODE == kModeRange) ? (f - key[0]) <= key[1] : f == key[0];
+                m |= (hit ? 1u : 0u) << j;
+            }
+            nlut[e] = (uint8_t)m;
+        }
+        __syncthreads();
     }
     uint32_t parity = 0; // DEPTH 2: which of the wave's two LDS buffers holds the current tile
     while (tile < tc.ntiles) {
@@ -614,6 +665,8 @@ __global__ __launch_bounds__(kBlockThreads, (DEPTH == 1 ? scan_occ<C, VPL, MODE>
             for (int q = 0; q < NK; q++)
 #pragma unroll
                 for (int j = 0; j < WORDS; j++) res[q][j] = x;
+        } else if constexpr (LK > 0) {
+            decode_words_narrow<C, VPL, LK, G::LANE_DWORDS>(w, res, nlut);
         } else {
             decode_words<C, VPL, 0, NK, MODE, G::LANE_DWORDS>(w, res, key);
         }
