@@ -454,7 +454,11 @@ int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n,
         if (((uintptr_t)out_dev & 15) != 0 || (stride_bytes & 15) != 0)
             return fail(MI355_E_INVALID, "out_dev and stride_bytes must be multiples of 16");
         if (stride_bytes < bitmap_bytes(n)) return fail(MI355_E_INVALID, "stride_bytes smaller than ceil(n/8)");
+    } else if (((uintptr_t)out_dev & 15) != 0) {
+        return fail(MI355_E_INVALID, "out_dev must be 16-byte aligned");
     }
+    // one predicate: both layouts are the plain bitmap of that key -- the equality scan kernel does it at twice the speed
+    if (P == 1) return scan_common_dev(ctx, kOpScanEq, packed_dev, n, c, (uint32_t)keys_host[0], 0, out_dev, hits_dev);
     LaunchReq r{};
     r.op = kOpSharedScan;
     r.c = c;

@@ -1075,6 +1075,25 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                     else
                         dst[j * 64 + lane] = st[j * 64 + lane];
                 }
+            } else if (!MULTI && P == 4) {
+                // 4 keys: a group's row is the dword of keys 0..3; the lane's GROUPS rows are contiguous
+                u32x4 *dst = (u32x4 *)(a.out + g0 * 4);
+#pragma unroll
+                for (int g = 0; g < GROUPS; g += 4) {
+                    u32x4 v = {res[2 * g], res[2 * g + 2], res[2 * g + 4], res[2 * g + 6]};
+                    dst[g / 4] = v;
+                }
+            } else if (!MULTI && P == 2) {
+                // 2 keys: a row is 2 bytes; rows of two groups share a dword (v_perm_b32: bytes 0,1 of each source)
+                u32x4 *dst = (u32x4 *)(a.out + g0 * 2);
+#pragma unroll
+                for (int g = 0; g < GROUPS; g += 8) {
+                    u32x4 v = {__builtin_amdgcn_perm(res[2 * g + 2], res[2 * g], 0x05040100u),
+                               __builtin_amdgcn_perm(res[2 * g + 6], res[2 * g + 4], 0x05040100u),
+                               __builtin_amdgcn_perm(res[2 * g + 10], res[2 * g + 8], 0x05040100u),
+                               __builtin_amdgcn_perm(res[2 * g + 14], res[2 * g + 12], 0x05040100u)};
+                    dst[g / 8] = v;
+                }
             } else {
                 const uint32_t nk = (P - pass * 8) < 8 ? (P - pass * 8) : 8;
 #pragma unroll

@@ -207,12 +207,14 @@ class ScanEngine:
     def shared_scan(self, keys: Sequence[int], col: PackedColumn, layout: str = "per_predicate",
                     out: Optional[torch.Tensor] = None, hits: Optional[torch.Tensor] = None):
         """per_predicate -> uint8[P, stride] (row k = bitmap of keys[k], stride = ceil(n/8) rounded up to 16);
-        linear -> uint8[ceil(n/8) * P] with the byte of 8-value group g and key k at g*P + k."""
+        linear -> uint8[ceil(n/8) * P] with the byte of 8-value group g and key k at g*P + k.
+        hits: int64[P] device tensor to fill (allocated when None); False skips the hit counts."""
         k = np.ascontiguousarray(np.asarray(keys, dtype=np.int64).astype(np.int32))
         P = int(k.shape[0])
         nb = (col.n + 7) // 8
         if hits is None:
             hits = torch.empty(P, dtype=torch.int64, device=self._dev)
+        hits_ptr = 0 if hits is False else hits.data_ptr()  # hits=False: bitmaps only, no counting
         if layout == "per_predicate":
             stride = (nb + 15) // 16 * 16
             if out is None:
@@ -226,5 +228,5 @@ class ScanEngine:
         else:
             raise ValueError(layout)
         check(lib().mi355_shared_scan_eq_dev(self._ctx, col.data.data_ptr(), col.n, col.c, k.ctypes.data, P, code,
-                                             out.data_ptr(), stride, hits.data_ptr()))
-        return out, hits
+                                             out.data_ptr(), stride, hits_ptr))
+        return out, (None if hits is False else hits)
