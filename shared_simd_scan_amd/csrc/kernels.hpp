@@ -1270,6 +1270,214 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
     hits_finalize(a, P, lane);
 }
 
+// ---- shared scan, P > 8: 32 predicates per LDS lookup -----------------------------------------------
+// With byte entries a scan over P keys does P/8 lookups per value, and at P >= 32 those lookups (random
+// ds_read_u8, ~5 LDS cycles each per CU) bound the kernel at ~3.7e12 lookups/s.  Here the tables hold DWORD
+// entries -- bit (k % 32) of entry[v] of table k / 32 is set iff v == key[k] -- so one ds_read_b32 answers 32
+// predicates: the 8 dwords of an 8-value group are split into their 4 key-bytes with two 4x4 byte transposes
+// (v_perm_b32), and each key-byte's (value x key) 8x8 bit matrix is transposed as in shared_lut_kernel.
+//   C <= 10: one table of 2^C dwords per 32 keys; C > 10: ceil(C/8) byte-digit tables of 256 dwords, ANDed.
+// LAYOUT 0: per-predicate bitmaps, pass-major (a wave-store is 512 B contiguous per key).
+// LAYOUT 1: linear; every 8-value group's row of P bytes is written start to end, 32 bytes per lookup round.
+template <int C> struct WideLutGeom {
+    static constexpr int ND = C <= 10 ? 1 : (C + 7) / 8;
+    static constexpr bool SINGLE = ND == 1;
+    static constexpr int DIGIT_BITS = SINGLE ? C : 8;
+    static constexpr int ENTRIES = 1 << DIGIT_BITS;
+    static constexpr int TABLE_DWORDS = ND * ENTRIES; // per pass of 32 keys
+    static constexpr int TABLE_BYTES = TABLE_DWORDS * 4;
+    static __device__ __forceinline__ uint32_t digit(uint32_t x, int d)
+    {
+        return (d == ND - 1) ? (x >> (DIGIT_BITS * d)) : ((x >> (DIGIT_BITS * d)) & (uint32_t)(ENTRIES - 1));
+    }
+    static __device__ __forceinline__ uint32_t lookup(const uint32_t *table, uint32_t x)
+    {
+        if constexpr (SINGLE) {
+            return table[x];
+        } else {
+            uint32_t m = table[digit(x, 0)];
+#pragma unroll
+            for (int d = 1; d < ND; d++) m &= table[d * ENTRIES + digit(x, d)];
+            return m;
+        }
+    }
+};
+
+template <int C, int AUX_, int VPL, int LAYOUT>
+__global__ __launch_bounds__(kBlockThreads) void shared_wide_kernel(ScanArgs a)
+{
+    using G = ScanGeom<C, VPL>;
+    using L = WideLutGeom<C>;
+    constexpr int WORDS = G::WORDS;
+    constexpr int GROUPS = VPL / 8;
+    constexpr int AUX = AUX_ & 15;
+    constexpr int NTS = (AUX_ & 16) ? 1 : 0; // non-temporal result stores
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+    __shared__ uint32_t s_hits[kMaxKeys]; // per-block hit counters (block_hits_add8)
+    uint32_t *const lut = (uint32_t *)mi355_dyn_lds; // ceil(P/32) * TABLE_BYTES dynamic bytes
+    for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxKeys; k += kBlockThreads) s_hits[k] = 0;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t P = a.nkeys;
+    const uint32_t npass32 = (P + 31) / 32;
+
+    // the tile's DMA does not depend on the tables: get it going first
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+
+    for (uint32_t i = threadIdx.x; i < npass32 * L::TABLE_DWORDS; i += kBlockThreads) lut[i] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) {
+        const uint32_t key = (uint32_t)a.keys_dev[k];
+        const bool in_range = C == 32 || (key >> (C & 31)) == 0;
+        if (in_range) {
+#pragma unroll
+            for (int d = 0; d < L::ND; d++) {
+                const uint32_t e = L::SINGLE ? key : L::digit(key, d);
+                __hip_atomic_fetch_or(lut + (k >> 5) * L::TABLE_DWORDS + d * L::ENTRIES + e, 1u << (k & 31), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+
+    // (value x 32 keys) dwords of one 8-value group -> for each key-byte b the transposed pair: byte q of
+    // (lo, hi) = bitmap byte of key 8b + q for this group
+    // (nb = key-bytes in use, 1..4: the last table of a scan over P keys may be partly empty)
+    auto group32 = [&](const uint32_t *table, const uint32_t (&x)[VPL], int g, int valid, bool tail, uint32_t nb, uint32_t (&Y)[4][2]) {
+        uint32_t m[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            m[i] = L::lookup(table, x[8 * g + i]);
+            if (tail) m[i] = (8 * g + i < valid) ? m[i] : 0u;
+        }
+        const uint32_t r0[4] = {m[0], m[1], m[2], m[3]}, r1[4] = {m[4], m[5], m[6], m[7]};
+        uint32_t lo4[4], hi4[4];
+        transpose4x4_bytes(r0, lo4);
+        transpose4x4_bytes(r1, hi4);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint32_t lo = lo4[b], hi = hi4[b];
+            if ((uint32_t)b < nb) transpose8x8(lo, hi);
+            Y[b][0] = lo;
+            Y[b][1] = hi;
+        }
+    };
+
+    while (tile < tc.ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t w[G::LANE_DWORDS];
+        read_lane_data<C, VPL>(lds_wave, lane, w);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint64_t next = tile + stride;
+        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        const bool full = tile < tc.nfull;
+        uint32_t xs[VPL];
+        extract_all<C, VPL, 0, G::LANE_DWORDS>(w, xs);
+        const int64_t left = (int64_t)(tc.n - tile * G::TILE_VALUES) - (int64_t)lane * VPL;
+        const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
+
+        if constexpr (LAYOUT == 1) {
+            if (full) {
+                const uint64_t g0 = tile * G::BITMAP_BYTES + (uint64_t)lane * GROUPS;
+#pragma unroll
+                for (int g = 0; g < GROUPS; g++) {
+                    uint8_t *row = a.out + (g0 + g) * P;
+                    for (uint32_t p32 = 0; p32 < npass32; p32++) {
+                        uint32_t Y[4][2];
+                        const uint32_t nk = (P - p32 * 32) < 32 ? (P - p32 * 32) : 32;
+                        group32(lut + p32 * L::TABLE_DWORDS, xs, g, VPL, false, (nk + 7) / 8, Y);
+                        uint8_t *dst = row + p32 * 32;
+                        if (nk == 32) {
+                            Unaligned128 v0, v1;
+                            v0.w[0] = Y[0][0]; v0.w[1] = Y[0][1]; v0.w[2] = Y[1][0]; v0.w[3] = Y[1][1];
+                            v1.w[0] = Y[2][0]; v1.w[1] = Y[2][1]; v1.w[2] = Y[3][0]; v1.w[3] = Y[3][1];
+                            *(Unaligned128 *)dst = v0;
+                            *(Unaligned128 *)(dst + 16) = v1;
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < 4; b++) {
+                                if ((uint32_t)(8 * b + 8) <= nk) {
+                                    store8_unaligned(dst + 8 * b, Y[b][0], Y[b][1]);
+                                } else {
+#pragma unroll
+                                    for (int q = 0; q < 8; q++)
+                                        if ((uint32_t)(8 * b + q) < nk) dst[8 * b + q] = (uint8_t)(Y[b][q >> 2] >> (8 * (q & 3)));
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // pass-major: per-predicate stores, hit counts, tail tiles
+        if (LAYOUT == 0 || !full || a.hits) {
+            for (uint32_t p32 = 0; p32 < npass32; p32++) {
+                const uint32_t *table = lut + p32 * L::TABLE_DWORDS;
+                uint32_t Yb[4][GROUPS][2];
+                const uint32_t nb32 = ((P - p32 * 32) < 32 ? (P - p32 * 32) + 7 : 39) / 8;
+#pragma unroll
+                for (int g = 0; g < GROUPS; g++) {
+                    uint32_t Y[4][2];
+                    group32(table, xs, g, valid, !full, nb32, Y);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) { Yb[b][g][0] = Y[b][0]; Yb[b][g][1] = Y[b][1]; }
+                }
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t pass = p32 * 4 + b;
+                    if (pass * 8 < P) {
+                        uint32_t out[8][WORDS];
+                        lut_gather_keys<VPL>(Yb[b], out);
+                        uint32_t cnt[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            cnt[q] = 0;
+#pragma unroll
+                            for (int j = 0; j < WORDS; j++) cnt[q] += __builtin_popcount(out[q][j]);
+                        }
+                        if (a.hits) block_hits_add8(s_hits, pass * 8, P, cnt, lane);
+                        if (full) {
+                            if constexpr (LAYOUT == 0) {
+                                uint8_t *dst = a.out + (uint64_t)(pass * 8) * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4);
+#pragma unroll
+                                for (int q = 0; q < 8; q++) {
+                                    if (pass * 8 + q < P) store_words<WORDS, NTS>(dst, out[q]);
+                                    dst += a.out_stride;
+                                }
+                            }
+                        } else {
+                            // tail tile: lookups of values >= n were zeroed; the bitmap is written byte-exact
+                            const int nbytes = (valid + 7) / 8;
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                const uint32_t k = pass * 8 + q;
+                                if (k < P) {
+                                    uint8_t *dst = LAYOUT == 0
+                                                       ? a.out + (uint64_t)k * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4)
+                                                       : a.out + (tile * G::BITMAP_BYTES + (uint64_t)lane * GROUPS) * P + k;
+                                    const uint64_t bstride = LAYOUT == 0 ? 1 : P;
+#pragma unroll
+                                    for (int bb = 0; bb < WORDS * 4; bb++)
+                                        if (bb < nbytes) dst[(uint64_t)bb * bstride] = (uint8_t)(out[q][bb >> 2] >> (8 * (bb & 3)));
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        tile = next;
+    }
+    if (a.hits) block_hits_flush(a, s_hits, P);
+    hits_finalize(a, P, lane);
+}
+
 // ---- IN-list scan: bitmap[i] = (value_i in {keys}) ----------------------------------------------------
 // One result bitmap for a set of keys (the OR-reduction of a shared scan).
 //   C <= 16: the set is a 2^C-bit bitset in LDS (<= 8 KiB) built by the block; one byte lookup + bit extract per value.

@@ -38,8 +38,15 @@ inline int scan_bpc(int occ_bpc, int tile_bytes, const LaunchReq &r)
 // static LDS of the multi-pass LUT kernel: four tiles, the per-block hit counters, ticket word and slack
 template <int C, int VPL> constexpr size_t lut_static_lds() { return 4 * ScanGeom<C, VPL>::LDS_BYTES + kMaxKeys * 4 + 512; }
 
-// the multi-pass LUT kernel needs ceil(P/8) tables next to that in the CU's 160 KiB of LDS
+// the 32-keys-per-lookup kernel needs ceil(P/32) tables next to that in the CU's 160 KiB of LDS
 template <int C, int VPL> bool lut_fits(uint32_t P)
+{
+    const size_t tables = (size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES;
+    return tables + lut_static_lds<C, VPL>() <= 160 * 1024;
+}
+
+// ... and the byte-entry multi-pass kernel ceil(P/8) tables
+template <int C, int VPL> bool lut8_fits(uint32_t P)
 {
     const size_t tables = ((size_t)((P + 7) / 8) * LutGeom<C, true>::TABLE_BYTES + 15) / 16 * 16;
     return tables + lut_static_lds<C, VPL>() <= 160 * 1024;
@@ -98,30 +105,36 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 hipLaunchKernelGGL((shared_lut_kernel<C, 18, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
             else
                 hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
-        } else if (lut_fits<C, VPL>(P)) { // one lookup table per pass of 8 keys, in dynamic LDS
+        } else if (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) {
+            // linear rows of fewer than ~200 keys without hit counts: byte-entry tables, 16 output bytes per round
+            // (measured, tools/sweep_p.py, 2.5e8 x 9 bit: P = 16 / 32 / 64 / 128 0.21 / 0.43 / 0.72 / 1.45 ms against
+            // 0.41 / 0.58 / 0.91 / 1.50 for the dword-entry kernel, which wins from P = 256: 2.80 against 3.16 ms)
             const size_t dyn = ((size_t)((P + 7) / 8) * LutGeom<C, true>::TABLE_BYTES + 15) / 16 * 16;
-            if (linear) {
-                static const bool attr = ((void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 2, VPL, 1, true>,
-                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - lut_static_lds<C, VPL>())), true);
-                (void)attr;
-                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, true>), dim3(grid_for(ntiles, lut_bpc(8), r.num_cus)),
-                                   dim3(kBlockThreads), dyn, r.stream, r.scan);
-            } else {
-                static const bool attr = ((void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 2, VPL, 0, true>,
-                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - lut_static_lds<C, VPL>())),
-                                          (void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 18, VPL, 0, true>,
-                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - lut_static_lds<C, VPL>())), true);
-                (void)attr;
-                // measured at P = 64, 1e9 x 9 bit: two blocks per CU 2.28 ms, one 2.59 (the passes are VALU-heavy: a
-                // second wave per SIMD fills the issue slots); the linear layout prefers one (3.00 against 3.36 ms)
-                const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : 2;
-                if (nt_stores)
-                    hipLaunchKernelGGL((shared_lut_kernel<C, 18, VPL, 0, true>), dim3(grid_for(ntiles, want, r.num_cus)),
-                                       dim3(kBlockThreads), dyn, r.stream, r.scan);
-                else
-                    hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, true>), dim3(grid_for(ntiles, want, r.num_cus)),
-                                       dim3(kBlockThreads), dyn, r.stream, r.scan);
-            }
+            static const bool attr8 = ((void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 2, VPL, 1, true>,
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                 (int)(160 * 1024 - lut_static_lds<C, VPL>())), true);
+            (void)attr8;
+            hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, true>), dim3(grid_for(ntiles, lut_bpc(8), r.num_cus)),
+                               dim3(kBlockThreads), dyn, r.stream, r.scan);
+        } else if (lut_fits<C, VPL>(P)) { // one dword-entry lookup table per 32 keys, in dynamic LDS
+            const size_t dyn = (size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES;
+            const int max_dyn = (int)(160 * 1024 - lut_static_lds<C, VPL>());
+            static const bool attr = ((void)hipFuncSetAttribute((const void *)shared_wide_kernel<C, 2, VPL, 1>,
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn),
+                                      (void)hipFuncSetAttribute((const void *)shared_wide_kernel<C, 2, VPL, 0>,
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn),
+                                      (void)hipFuncSetAttribute((const void *)shared_wide_kernel<C, 18, VPL, 0>,
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn),
+                                      true);
+            (void)attr;
+            const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : 2;
+            const dim3 grid(grid_for(ntiles, want, r.num_cus));
+            if (linear)
+                hipLaunchKernelGGL((shared_wide_kernel<C, 2, VPL, 1>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+            else if (nt_stores)
+                hipLaunchKernelGGL((shared_wide_kernel<C, 18, VPL, 0>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+            else
+                hipLaunchKernelGGL((shared_wide_kernel<C, 2, VPL, 0>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
         } else { // more keys than the tables hold: compare chain, ceil(P/8) passes over the registers
             static const int bpc = blocks_per_cu(shared_general_kernel<C, 2, VPL>);
             hipLaunchKernelGGL((shared_general_kernel<C, 2, VPL>), dim3(grid_for(ntiles, cap_bpc(bpc, r), r.num_cus)), dim3(kBlockThreads), 0,

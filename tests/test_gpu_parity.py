@@ -249,6 +249,26 @@ def test_shared_scan_predicate_counts(O, eng, P, layout):
     assert np.array_equal(hits.cpu().numpy().astype(np.uint64), ohits)
 
 
+@pytest.mark.parametrize("P", [2, 4, 8, 9, 16, 37, 64, 128, 191, 192, 300])
+@pytest.mark.parametrize("layout", ["per_predicate", "linear"])
+@pytest.mark.parametrize("c", [9, 13])
+def test_shared_scan_without_hit_counts(O, eng, c, P, layout):
+    """the reference's shared scans return no counts (src/simd_scan.hpp:102-120): with hits = NULL the launcher may
+    pick other kernels (byte-entry tables for linear rows below 192 keys) -- same bitmaps required"""
+    n = 3 * 8192 + 2049
+    vals, col = make_column(O, eng, n, c, 77 + c + P)
+    packed_host = col.data.cpu().numpy()
+    keys = [int(v) for v in np.random.default_rng(P + c).integers(0, 1 << c, size=P)]
+    keys[0] = int(vals[5])
+    out, hits = eng.shared_scan(keys, col, layout=layout, hits=False)
+    assert hits is None
+    oout, _ = O.shared_scan_eq(packed_host, n, c, keys, layout)
+    got = out.cpu().numpy()
+    if layout == "per_predicate":
+        got = got[:, :(n + 7) // 8]
+    assert np.array_equal(got, oout)
+
+
 @pytest.mark.parametrize("nts", [0, 1])
 @pytest.mark.parametrize("c", [7, 9, 16, 21])
 def test_store_policy_variants_agree(O, eng, c, nts):
