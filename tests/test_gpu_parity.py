@@ -402,6 +402,45 @@ def test_cfg2_1e9_properties(O, eng):
         assert np.array_equal(bm[a // 8: a // 8 + (ln + 7) // 8].cpu().numpy(), obm)
 
 
+@pytest.mark.parametrize("c", [3, 9])
+def test_more_than_2_pow_32_rows(O, eng, c):
+    """row indices, tile indices and byte offsets are 64-bit all the way: 2^32 + 3*8192 + 77 rows (a ragged tail tile),
+    generator v[i] = i % 7.  Hit counts exact; oracle windows at the start, across row 2^32 and over the ragged end;
+    decompress and the selection vector (row ids > 2^32) checked on the last rows."""
+    import torch
+
+    n = (1 << 32) + 3 * 8192 + 77
+    col = eng.generate("mod", n, c, 7)
+    key = 5
+    bm, hits = eng.scan(key, col)
+    assert int(hits.item()) == (n - 1 - key) // 7 + 1
+    lo, hi = 2, 4
+    bmr, hitsr = eng.scan_range(lo, hi, col)
+    assert int(hitsr.item()) == sum((n - 1 - k) // 7 + 1 for k in range(lo, hi + 1))
+    assert int(eng.bitmap_count(bm, n).item()) == int(hits.item())
+    a0 = (1 << 32) - 8192 * 2
+    for a, ln in ((0, 100_000), (a0, 8192 * 4 + 96), (n - 77 - 8192, None)):
+        ln = n - a if ln is None else ln
+        pk = col.data[a * c // 8: a * c // 8 + (ln * c + 7) // 8].cpu().numpy()
+        vals = ((np.arange(a, a + ln, dtype=np.uint64)) % 7).astype(np.uint32)
+        assert np.array_equal(pk, O.pack(vals, c)[: pk.shape[0]])
+        obm, _ = O.scan_eq(pk, ln, c, key)
+        assert np.array_equal(bm[a // 8: a // 8 + (ln + 7) // 8].cpu().numpy(), obm)
+        obm, _ = O.scan_range(pk, ln, c, lo, hi)
+        assert np.array_equal(bmr[a // 8: a // 8 + (ln + 7) // 8].cpu().numpy(), obm)
+    del bmr
+    # selection vector of the tail: rows >= 2^32 with v == key
+    tail_rows = n - (1 << 32)
+    sub = bm[(1 << 32) // 8:].clone()
+    ids, cnt = eng.bitmap_to_rowids(sub, tail_rows, capacity=tail_rows, first_row=1 << 32)
+    k = int(cnt.item())
+    expect = np.arange(1 << 32, n, dtype=np.uint64)
+    expect = expect[expect % 7 == key]
+    assert k == expect.shape[0] and np.array_equal(ids[:k].cpu().numpy().astype(np.uint64), expect)
+    del bm, sub, col
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("c,n", [(5, 100_000_000), (7, 100_000_000), (9, 100_000_000), (12, 100_000_000),
                                  (17, 100_000_000), (21, 100_000_000), (12, 1_000_000_000), (21, 1_000_000_000)])
 def test_cfg3_width_sweep_range_properties(O, eng, c, n):
