@@ -8,6 +8,7 @@ A "step" is one pass of the hot path (one scan_eq launch: bitmap + hit count) ov
 row-range shard, the column already resident in HBM.  Weak scaling: every rank owns --rows rows
 (default 1e9; rank r holds global rows [r*rows, (r+1)*rows)); no data-path collective inside the timed
 region.  The RCCL bitmap gather is timed separately after it and reported as `gather_ms`.
+`--scaling strong` splits ONE column of --rows rows over the ranks instead (8192-row-aligned ranges).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "measurement" for every field).
 """
@@ -35,6 +36,8 @@ def parse():
     ap.add_argument("--workload", choices=["scan_eq", "scan_range", "shared_scan", "decompress"], default="scan_eq")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --rows per GPU; strong: --rows in total, row-range sharded at 8192-row boundaries")
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the multi-core CPU leg (box share: 16)")
     return ap.parse_args()
@@ -137,6 +140,12 @@ def main():
     eng = ScanEngine(local_rank)
     n, c = args.rows, args.bits
     first = rank * n
+    total_rows = world * n
+    if args.scaling == "strong":  # one column of --rows rows split over the ranks
+        from shared_simd_scan_amd.sharded import shard_rows
+
+        first, last = shard_rows(args.rows, world)[rank]
+        n, total_rows = last - first, args.rows
     mask = (1 << c) - 1
     if args.column == "mod5":
         col = eng.generate("mod", n, c, 5, first_row=first)
@@ -209,24 +218,30 @@ def main():
         got = int(hits.item())
         assert got == expect_hits, f"hits {got} != {expect_hits}"
 
-    gather_ms = None
+    gather_ms, gather_error = None, None
     if world > 1 and not args.no_gather and args.workload in ("scan_eq", "scan_range"):
         # final exchange step of the north star: per-shard bitmaps -> rank 0 (RCCL over xGMI)
         from shared_simd_scan_amd.sharded import gather_bitmaps
 
-        full = gather_bitmaps(bitmap[:nb], dst=0)  # warm
-        sync_all()
-        g0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            full = gather_bitmaps(bitmap[:nb], dst=0, out=full)
-        sync_all()
-        gather_ms = (time.perf_counter() - g0) / reps * 1e3
-        gather_ms = reduce_max(gather_ms)
+        sizes = None
+        if args.scaling == "strong":
+            sizes = [(b - a + 7) // 8 for a, b in shard_rows(args.rows, world)]
+        try:
+            full = gather_bitmaps(bitmap[:nb], dst=0, sizes=sizes)  # warm
+            sync_all()
+            g0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                full = gather_bitmaps(bitmap[:nb], dst=0, out=full, sizes=sizes)
+            sync_all()
+            gather_ms = (time.perf_counter() - g0) / reps * 1e3
+            gather_ms = reduce_max(gather_ms)
+        except Exception as e:  # the scan figures above stand on their own; report the exchange step as failed
+            gather_error = f"{type(e).__name__}: {e}"
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * n / (elapsed / args.steps)
+        value = total_rows / (elapsed / args.steps)
         achieved = algo_bytes / (dev_ms * 1e-3) / 1e9
         line = {
             # BASELINE.json: "scanned values/sec + achieved HBM GB/s, 1e9 x 9-bit column, 1/2/4/8 GPU";
@@ -234,7 +249,7 @@ def main():
             "metric": "scanned values/sec + achieved HBM GB/s, 1e9 x 9-bit column (equality scan, bitmap + hit count out)"
             if args.workload == "scan_eq" and c == 9 and n == 1_000_000_000 else f"{args.workload} values/sec, {n:.0e} x {c}-bit column",
             "value": value, "unit": "values/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32" if args.workload != "decompress" else "i32", "data": "synthetic",
             "config": {"workload": f"{args.workload} {n:.0e}x{c}bit per GPU, column={args.column}, key={key}",
                        "rows_per_gpu": n, "bits": c, "parallelism": f"row-range shards x{world}"},
@@ -247,8 +262,10 @@ def main():
         }
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
-            line["gather_gb_per_s"] = (world - 1) * nb / (gather_ms * 1e-3) / 1e9
-            line["end_to_end_values_per_s"] = world * n / ((ms_per_step + gather_ms) * 1e-3)
+            line["gather_gb_per_s"] = (total_rows / 8 - nb) / (gather_ms * 1e-3) / 1e9
+            line["end_to_end_values_per_s"] = total_rows / ((ms_per_step + gather_ms) * 1e-3)
+        if gather_error is not None:
+            line["gather_error"] = gather_error
         if world == 1 and not args.no_cpu_baseline and args.workload == "scan_eq":
             line["cpu_baseline"] = cpu_baseline(args, col, bitmap, key)
         print(json.dumps(line), flush=True)
