@@ -119,6 +119,17 @@ int main(int argc, char **argv)
                       }, {1, 2}, read_bytes + n / 8.0});
     }
     {
+        constexpr int VPL = scan_vpl(C, kModeRange);
+        using G = ScanGeom<C, VPL>;
+        const uint64_t ntiles = (n + G::TILE_VALUES - 1) / G::TILE_VALUES;
+        ScanArgs sr = sa;
+        sr.key[0] = (1u << C) / 4;                          // lo
+        sr.key[1] = (uint32_t)((1ull << C) / 2 - (1u << C) / 4); // hi - lo   (BASELINE config 3: [2^c/4, 2^c/2])
+        vs.push_back({"scan_range (product)", [=](int bpc, hipStream_t s) {
+                          hipLaunchKernelGGL((scan_kernel<C, kModeRange, 2, VPL>), dim3(grid_of(ntiles, bpc)), dim3(kBlockThreads), 0, s, sr);
+                      }, {1, 2}, read_bytes + n / 8.0});
+    }
+    {
         const uint64_t nsteps = (uint64_t)(read_bytes / (C * 1024));
         vs.push_back({"mix C:1", [=](int bpc, hipStream_t s) {
                           hipLaunchKernelGGL((mix_kernel<C, 1, 0>), dim3(bpc * cus), dim3(256), 0, s, (const u32x4 *)packed, (u32x4 *)out, nsteps);

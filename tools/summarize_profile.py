@@ -81,6 +81,20 @@ def main():
                                               "read": out["hbm_read_bytes_per_launch"],
                                               "write": out["hbm_write_bytes_per_launch"], "source": os.path.basename(base) + ".json"}
         json.dump(table, open(tpath, "w"), indent=1)
+    # the JSON line bench.py printed in pass 1 (its roofline.kernel_ms comes from HIP events in the SAME run as the
+    # --stats average above) and the raw --stats kernel table
+    log = os.path.join(src, "stats.log")
+    if os.path.exists(log):
+        lines = [ln for ln in open(log) if ln.startswith("{") and '"roofline"' in ln]
+        if lines:
+            bench = json.loads(lines[-1])
+            json.dump(bench, open(os.path.join(ROOT, "profiles", f"{tag}_{workload}_bench_under_rocprof.json"), "w"), indent=1)
+            if stats:
+                with open(base + ".md", "a") as f:
+                    f.write(f"\nbench.py in the same run: HIP-event kernel time {bench['roofline']['kernel_ms'] * 1e6:.0f} ns per launch, "
+                            f"wall {bench['ms_per_step'] * 1e6:.0f} ns per step (rocprofv3 average above: {float(stats['AverageNs']):.0f} ns)\n")
+    for f in newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+        open(os.path.join(ROOT, "profiles", f"{tag}_{workload}_kernel_stats.csv"), "w").write(open(f).read())
     print(open(base + ".md").read())
 
 
