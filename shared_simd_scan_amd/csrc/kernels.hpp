@@ -67,13 +67,16 @@ enum ScanMode { kModeEq = 0, kModeRange = 1, kModeShared = 2 };
 
 // occupancy target handed to the register allocator: what LDS admits, but the 8-key shared scan keeps
 // 8 accumulators + 8x(VPL/32) result words + hit counters live and wants up to 128 VGPRs
+// values per LDS table lookup of the narrow-width decode (see decode_words_narrow); 0 = compare chain
+template <int C> constexpr int narrow_k() { return C == 1 ? 8 : (C <= 3 ? 4 : (C <= 5 ? 3 : (C <= 7 ? 2 : 0))); }
+
 template <int C, int VPL, int MODE> constexpr int scan_occ()
 {
     constexpr int lds = ScanGeom<C, VPL>::OCC;
     if (MODE != 2 && C <= 7) {
         // table-lookup decode (narrow_k): many lookups in flight, the predicate table (<= 16 KiB) sits next to the
         // tiles, and the launcher runs 1-2 blocks per CU anyway
-        const int with_table = (160 * 1024) / (4 * ScanGeom<C, VPL>::LDS_BYTES + (1 << (2 * C)) + 64);
+        const int with_table = (160 * 1024) / (4 * ScanGeom<C, VPL>::LDS_BYTES + (1 << (narrow_k<C>() * C)) + 64);
         return with_table > 4 ? 4 : (with_table < 1 ? 1 : with_table);
     }
     return MODE == 2 ? (lds > 4 ? 4 : lds) : lds;
@@ -137,6 +140,20 @@ __device__ __forceinline__ void dma_tile_partial(const uint8_t *src, uint64_t by
 }
 
 // ---- value extraction at a compile-time position -------------------------------------------
+// LEN bits starting at compile-time bit position BIT of the lane's dwords
+template <int BIT, int LEN, int NW> __device__ __forceinline__ uint32_t extract_at(const uint32_t (&w)[NW])
+{
+    constexpr int d = BIT >> 5;
+    constexpr int s = BIT & 31;
+    if constexpr (LEN == 32 && s == 0) {
+        return w[d];
+    } else if constexpr (s + LEN <= 32) {
+        return __builtin_amdgcn_ubfe(w[d], s, LEN);
+    } else {
+        return __builtin_amdgcn_alignbit(w[d + 1], w[d], s) & (LEN == 32 ? 0xffffffffu : ((1u << (LEN & 31)) - 1u));
+    }
+}
+
 template <int C, int K, int NW> __device__ __forceinline__ uint32_t extract(const uint32_t (&w)[NW])
 {
     constexpr int bit = K * C;
@@ -474,27 +491,30 @@ __device__ __forceinline__ void block_hits_flush(const ScanArgs &a, uint32_t *s_
 // HBM stream leaves per value below ~8 bits (1e9 x 5 bit: 17 cycles per wave-value at 6 TB/s).  For C <= 7 the
 // eq / range scans therefore evaluate LK values per step through a table in LDS: index = the LK*C packed bits of LK
 // consecutive values (one v_bfe_u32 / v_alignbit_b32), entry = their LK predicate bits, appended to the bitmap word
-// with one v_lshl_or_b32 -- ~9 cycles per LK values.  The block builds the 2^(LK*C)-entry table from the predicate
-// (<= 16 KiB at C = 7) while its first tile's DMA is in flight.
-template <int C> constexpr int narrow_k() { return C == 1 ? 8 : (C <= 3 ? 4 : (C <= 7 ? 2 : 0)); }
+// with one v_lshl_or_b32 -- ~9 cycles per LK values.  LK = 8 / 4 / 4 / 3 / 3 / 2 / 2 for C = 1..7 (tables of 256 B to
+// 32 KiB; at C = 5 the lookups themselves are the next limit: 3 values per lookup instead of 2 took the scan from 90 %
+// to 95 % of a trivial kernel with the same byte mix, tools/ceilings.hip).  The
+// block builds the 2^(LK*C)-entry table from the predicate while its first tile's DMA is in flight.
+// one lookup: values [32J + LK*GI, +LEN) of the lane, LEN = LK except for the last group of a word when LK does not
+// divide 32 (its entry's upper bits describe fields that are not there: masked)
+template <int C, int LK, int J, int GI, int NW>
+__device__ __forceinline__ void narrow_step(const uint32_t (&w)[NW], uint32_t &acc, const uint8_t *table)
+{
+    constexpr int FIRST = LK * GI;
+    constexpr int LEN = (32 - FIRST) < LK ? (32 - FIRST) : LK;
+    uint32_t m = table[extract_at<(32 * J + FIRST) * C, LEN * C, NW>(w)];
+    if constexpr (LEN < LK) m &= (1u << LEN) - 1u;
+    acc = (acc << LEN) | m;
+    if constexpr (GI > 0) narrow_step<C, LK, J, GI - 1, NW>(w, acc, table);
+}
 
-template <int C, int K, int NW> __device__ __forceinline__ uint32_t extract(const uint32_t (&w)[NW]);
-template <int C, int VPL, int K, int NW> __device__ __forceinline__ void extract_all(const uint32_t (&w)[NW], uint32_t (&x)[VPL]);
-
-template <int C, int VPL, int LK, int NW>
+template <int C, int VPL, int LK, int J, int NW>
 __device__ __forceinline__ void decode_words_narrow(const uint32_t (&w)[NW], uint32_t (&res)[1][VPL / 32], const uint8_t *table)
 {
-    constexpr int NG = VPL / LK;  // lookups per lane and tile
-    constexpr int GPW = 32 / LK;  // lookups per bitmap word
-    uint32_t xs[NG];
-    extract_all<C * LK, NG, 0, NW>(w, xs);
-#pragma unroll
-    for (int j = 0; j < VPL / 32; j++) {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int g = GPW - 1; g >= 0; g--) acc = (acc << LK) | table[xs[j * GPW + g]];
-        res[0][j] = acc;
-    }
+    uint32_t acc = 0;
+    narrow_step<C, LK, J, (32 + LK - 1) / LK - 1, NW>(w, acc, table); // from the word's last group down to its first
+    res[0][J] = acc;
+    if constexpr (J + 1 < VPL / 32) decode_words_narrow<C, VPL, LK, J + 1, NW>(w, res, table);
 }
 
 // ---- the scan kernel ------------------------------------------------------------------------
@@ -666,7 +686,7 @@ __global__ __launch_bounds__(kBlockThreads, (DEPTH == 1 ? scan_occ<C, VPL, MODE>
 #pragma unroll
                 for (int j = 0; j < WORDS; j++) res[q][j] = x;
         } else if constexpr (LK > 0) {
-            decode_words_narrow<C, VPL, LK, G::LANE_DWORDS>(w, res, nlut);
+            decode_words_narrow<C, VPL, LK, 0, G::LANE_DWORDS>(w, res, nlut);
         } else {
             decode_words<C, VPL, 0, NK, MODE, G::LANE_DWORDS>(w, res, key);
         }
