@@ -161,6 +161,9 @@ int mi355_ctx_create(int device, void *hip_stream, mi355_ctx **out)
     if (e == hipSuccess) e = hipMemset(c->kernel_scratch, 0, kScratchWords * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&c->keys_scratch, (kMaxKeys + 8) * sizeof(int32_t));
     if (e != hipSuccess) {
+        (void)hipFree(c->hits_scratch); // hipFree(nullptr) is a no-op
+        (void)hipFree(c->kernel_scratch);
+        (void)hipFree(c->keys_scratch);
         delete c;
         return fail(MI355_E_HIP, "hipMalloc(scratch): %s", hipGetErrorString(e));
     }

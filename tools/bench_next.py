@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""tools/bench_next.py -- the steps either side of the scan on one GPU, each against its
+algorithmic HBM bytes: device packer / generators, bitmap combine / count / row-id materialisation, comparison
+predicates with a fused AND-mask, IN-lists.  HIP events around --reps back-to-back launches.
+usage: python tools/bench_next.py [--rows N] [--bits C] [--reps R]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1_000_000_000)
+    ap.add_argument("--bits", type=int, default=9)
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    import torch
+
+    from shared_simd_scan_amd import ScanEngine
+
+    eng = ScanEngine(0)
+    n, c = args.rows, args.bits
+    nb = (n + 7) // 8
+    pk = n * c / 8
+
+    def timed(fn, reps=args.reps):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def report(name, ms, nbytes, note=""):
+        print(f"{name:44s} {ms:8.4f} ms  {nbytes / ms / 1e6:7.0f} GB/s algorithmic  {n / ms * 1e3:.3e} rows/s  {note}", flush=True)
+
+    col = eng.generate("splitmix", n, c, 42)
+    report("generate splitmix (write packed)", timed(lambda: eng.generate("splitmix", n, c, 42), 5), pk)
+    vals = eng.decompress(col)  # int32[n]: input of the device packer
+    report("compress u32 -> packed", timed(lambda: eng.compress(vals, c), 5), 4 * n + pk)
+    del vals
+    torch.cuda.empty_cache()
+
+    key = 77
+    bm_a, hits = eng.scan_where("<", (1 << c) // 2, col)
+    bm_b, _ = eng.scan_where(">=", (1 << c) // 8, col)
+    out = torch.empty_like(bm_a)
+    h1 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for op in ("<", "!=", "between", "not_between"):
+        report(f"scan_where {op}", timed(lambda: eng.scan_where(op, (1 << c) // 4, col, b=(1 << c) // 2, bitmap=out, hits=h1)), pk + nb)
+    report("scan_where < AND mask (fused conjunction)",
+           timed(lambda: eng.scan_where("<", (1 << c) // 4, col, and_mask=bm_b, bitmap=out, hits=h1)), pk + 2 * nb)
+    for P in (4, 40, 400):
+        keys = [(37 * k + 3) % (1 << c) for k in range(P)]
+        report(f"scan_in P={P}", timed(lambda: eng.scan_in(keys, col, bitmap=out, hits=h1)), pk + nb)
+    report("bitmap_combine AND (+popcount)", timed(lambda: eng.bitmap_combine("and", bm_a, bm_b, n, out=out)), 3 * nb)
+    report("bitmap_count", timed(lambda: eng.bitmap_count(bm_a, n)), nb)
+    for name, bm in (("1/512", eng.scan(key, col)[0]), ("1/2", bm_a)):
+        cnt = int(eng.bitmap_count(bm, n).item())
+        ids = None
+
+        def f():
+            nonlocal ids
+            ids = eng.bitmap_to_rowids(bm, n, capacity=cnt)
+
+        report(f"bitmap_to_rowids selectivity {name}", timed(f, 5), nb + 8 * cnt, f"{cnt} ids")
+        del ids
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
