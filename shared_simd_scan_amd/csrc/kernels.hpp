@@ -1739,9 +1739,15 @@ static __global__ __launch_bounds__(1024) void rowid_scan_kernel(RowidArgs g)
     }
 }
 
+// Pass 3.  A step covers 64 lanes x 32 bits = 2048 rows.  Each lane expands its word into a wave-private LDS buffer
+// (16-bit offsets inside the step, at the position given by the wave prefix of the popcounts), then the wave copies
+// the buffer out with consecutive lanes writing consecutive ids (512 B per store instruction).  Expanding straight
+// into global memory made every store instruction touch up to 64 lines: 2.7 ms for 5e8 ids against 4 GB / 6 TB/s.
 static __global__ __launch_bounds__(256) void rowid_write_kernel(RowidArgs g)
 {
+    __shared__ uint16_t stage[4][2048];
     const int lane = threadIdx.x & 63;
+    uint16_t *const st = stage[threadIdx.x >> 6];
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t ch = wave; ch < g.nchunks; ch += nwaves) {
@@ -1764,15 +1770,22 @@ static __global__ __launch_bounds__(256) void rowid_write_kernel(RowidArgs g)
                 uint32_t t = __shfl_up(incl, d, 64);
                 if (lane >= d) incl += t;
             }
-            uint64_t pos = out + (incl - c);
-            const uint64_t row0 = g.first_row + o * 8;
+            const uint32_t total = __shfl(incl, 63, 64);
+            uint32_t pos = incl - c;
+            const uint32_t off0 = lane * 32; // row offset of the lane's bit 0 inside the step
             while (w) {
                 const int bit = __builtin_ctz(w);
                 w &= w - 1;
-                if (pos < g.capacity) g.rowids[pos] = row0 + bit;
-                pos++;
+                st[pos++] = (uint16_t)(off0 + bit);
             }
-            out += __shfl(incl, 63, 64);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's LDS writes are done (LDS is in order per wave)
+            const uint64_t row0 = g.first_row + (base + (uint64_t)k * 256) * 8;
+            for (uint32_t i = lane; i < total; i += 64) {
+                const uint64_t p = out + i;
+                if (p < g.capacity) g.rowids[p] = row0 + st[i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads done before the next step overwrites the buffer
+            out += total;
         }
     }
 }
