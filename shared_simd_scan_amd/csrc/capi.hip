@@ -306,8 +306,17 @@ static int pack_launch(mi355_ctx *ctx, int src, const void *values_dev, uint64_t
     uint64_t cap = (uint64_t)ctx->num_cus * 8;
     unsigned grid = (unsigned)(blocks < cap ? (blocks ? blocks : 1) : cap);
     switch (src) {
-    case kSrcU16: hipLaunchKernelGGL(pack_kernel<kSrcU16>, dim3(grid), dim3(256), 0, ctx->stream, a); break;
-    case kSrcU32: hipLaunchKernelGGL(pack_kernel<kSrcU32>, dim3(grid), dim3(256), 0, ctx->stream, a); break;
+#define PACK_BY_WIDTH(SRC)                                                                                          \
+    do { /* values per output dword: at most floor(31/c) + 2 */                                                    \
+        if (c >= 16) hipLaunchKernelGGL((pack_kernel<SRC, 3>), dim3(grid), dim3(256), 0, ctx->stream, a);          \
+        else if (c >= 8) hipLaunchKernelGGL((pack_kernel<SRC, 5>), dim3(grid), dim3(256), 0, ctx->stream, a);      \
+        else if (c >= 4) hipLaunchKernelGGL((pack_kernel<SRC, 9>), dim3(grid), dim3(256), 0, ctx->stream, a);      \
+        else if (c >= 2) hipLaunchKernelGGL((pack_kernel<SRC, 17>), dim3(grid), dim3(256), 0, ctx->stream, a);     \
+        else hipLaunchKernelGGL((pack_kernel<SRC, 32>), dim3(grid), dim3(256), 0, ctx->stream, a);                 \
+    } while (0)
+    case kSrcU16: PACK_BY_WIDTH(kSrcU16); break;
+    case kSrcU32: PACK_BY_WIDTH(kSrcU32); break;
+#undef PACK_BY_WIDTH
     case kSrcMod: hipLaunchKernelGGL(pack_kernel<kSrcMod>, dim3(grid), dim3(256), 0, ctx->stream, a); break;
     case kSrcSplitmix: hipLaunchKernelGGL(pack_kernel<kSrcSplitmix>, dim3(grid), dim3(256), 0, ctx->stream, a); break;
     case kSrcIndex: hipLaunchKernelGGL(pack_kernel<kSrcIndex>, dim3(grid), dim3(256), 0, ctx->stream, a); break;

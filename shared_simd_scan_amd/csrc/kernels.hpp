@@ -1905,37 +1905,92 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t seed, uint64_t i)
     return z ^ (z >> 31);
 }
 
-template <int SRC> __global__ __launch_bounds__(256) void pack_kernel(PackArgs a)
+// MAXK > 0 (packing from an array): an output dword draws on at most MAXK = floor(31/c) + 2 values; their loads are
+// issued together (predicated) instead of one per loop trip -- the trip-by-trip form was bound by load latency.
+template <int SRC, int MAXK = 0> __global__ __launch_bounds__(256) void pack_kernel(PackArgs a)
 {
     const uint32_t c = a.c;
     const uint32_t mask = c == 32 ? 0xffffffffu : ((1u << c) - 1u);
     const uint64_t gstride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t D = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; D < a.out_dwords; D += gstride) {
-        const uint64_t grp = D / c;
-        const uint32_t r = (uint32_t)(D - grp * c);
-        const uint32_t lo_bit = 32 * r;
-        const uint32_t k0 = lo_bit / c;
-        const uint32_t k1 = (lo_bit + 31) / c;
-        uint32_t word = 0;
-        for (uint32_t k = k0; k <= k1 && k < 32; k++) {
-            const uint64_t i = grp * 32 + k;
-            if (i >= a.n) break;
-            uint32_t v;
-            if constexpr (SRC == kSrcU16)
-                v = ((const uint16_t *)a.values)[i];
-            else if constexpr (SRC == kSrcU32)
-                v = ((const uint32_t *)a.values)[i];
-            else if constexpr (SRC == kSrcMod)
-                v = (uint32_t)((a.first_row + i) % a.param);
-            else if constexpr (SRC == kSrcSplitmix)
-                v = (uint32_t)splitmix64(a.param, a.first_row + i);
-            else
-                v = (uint32_t)(a.first_row + i);
-            v &= mask;
-            const int32_t pos = (int32_t)(k * c) - (int32_t)lo_bit; // bit position inside this dword
-            word |= pos >= 0 ? (v << pos) : (v >> (-pos));
+    uint64_t D = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (D >= a.out_dwords) return;
+    // (group, dword-in-group) of the thread's first dword by one division; later dwords advance incrementally.
+    // n / c for n < 1024 and c <= 32 is exactly (n * M) >> 16 with M = ceil(2^16 / c): no division in the loop.
+    uint64_t grp = D / c;
+    uint32_t r = (uint32_t)(D - grp * c);
+    const uint64_t step_grp = gstride / c;
+    const uint32_t step_r = (uint32_t)(gstride - step_grp * c);
+    const uint32_t M = (65536u + c - 1u) / c;
+    auto advance = [&](uint64_t &g_, uint32_t &r_) {
+        g_ += step_grp;
+        r_ += step_r;
+        if (r_ >= c) {
+            r_ -= c;
+            g_++;
         }
-        a.out[D] = word;
+    };
+    if constexpr (MAXK > 0) {
+        static_assert(SRC == kSrcU16 || SRC == kSrcU32, "batched loads are for array sources");
+        if (a.n == 0) { // only the pad: nothing to read
+            for (; D < a.out_dwords; D += gstride) a.out[D] = 0;
+            return;
+        }
+        // dword r_ of group g_: the (predicated) loads of its <= MAXK values are issued together
+        auto word_of = [&](uint64_t g_, uint32_t r_) {
+            const uint32_t lo_bit = 32 * r_;
+            const uint32_t k0 = (lo_bit * M) >> 16;
+            uint32_t k1 = ((lo_bit + 31) * M) >> 16;
+            k1 = k1 < 31 ? k1 : 31;
+            uint32_t vals[MAXK];
+#pragma unroll
+            for (int j = 0; j < MAXK; j++) {
+                const uint32_t k = k0 + j;
+                const uint64_t i = g_ * 32 + k;
+                uint32_t v = 0;
+                if (k <= k1 && i < a.n) v = SRC == kSrcU16 ? (uint32_t)((const uint16_t *)a.values)[i] : ((const uint32_t *)a.values)[i];
+                vals[j] = v & mask;
+            }
+            uint32_t word = 0;
+#pragma unroll
+            for (int j = 0; j < MAXK; j++) {
+                const int32_t pos = (int32_t)((k0 + j) * c) - (int32_t)lo_bit; // bit position inside this dword
+                word |= pos >= 0 ? (vals[j] << (pos & 31)) : (vals[j] >> ((-pos) & 31)); // vals[j] == 0 when unused
+            }
+            return word;
+        };
+        // (two dwords per iteration with unconditional clamped loads was measured: 1.59 ms against 1.28 ms per 1e9 values)
+        for (; D < a.out_dwords; D += gstride) {
+            a.out[D] = word_of(grp, r);
+            advance(grp, r);
+        }
+    } else {
+        for (; D < a.out_dwords; D += gstride) {
+            const uint32_t lo_bit = 32 * r;
+            const uint32_t k0 = (lo_bit * M) >> 16;
+            uint32_t k1 = ((lo_bit + 31) * M) >> 16;
+            k1 = k1 < 31 ? k1 : 31;
+            uint32_t word = 0;
+            for (uint32_t k = k0; k <= k1; k++) {
+                const uint64_t i = grp * 32 + k;
+                if (i >= a.n) break;
+                uint32_t v;
+                if constexpr (SRC == kSrcU16)
+                    v = ((const uint16_t *)a.values)[i];
+                else if constexpr (SRC == kSrcU32)
+                    v = ((const uint32_t *)a.values)[i];
+                else if constexpr (SRC == kSrcMod)
+                    v = (uint32_t)((a.first_row + i) % a.param);
+                else if constexpr (SRC == kSrcSplitmix)
+                    v = (uint32_t)splitmix64(a.param, a.first_row + i);
+                else
+                    v = (uint32_t)(a.first_row + i);
+                v &= mask;
+                const int32_t pos = (int32_t)(k * c) - (int32_t)lo_bit; // bit position inside this dword
+                word |= pos >= 0 ? (v << pos) : (v >> (-pos));
+            }
+            a.out[D] = word;
+            advance(grp, r);
+        }
     }
 }
 
