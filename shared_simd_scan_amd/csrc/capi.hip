@@ -97,6 +97,7 @@ int launch(mi355_ctx *ctx, LaunchReq &r)
 {
     if (int rc = bind(ctx)) return rc;
     r.stream = ctx->stream;
+    r.device = ctx->device;
     r.num_cus = ctx->num_cus;
     r.max_blocks_per_cu = ctx->max_blocks_per_cu;
     r.dma_aux = ctx->dma_aux;

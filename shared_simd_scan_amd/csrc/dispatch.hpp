@@ -14,6 +14,7 @@ struct LaunchReq {
     int op;
     unsigned c;
     hipStream_t stream;
+    int device;            // the context's device (per-device kernel attributes)
     int num_cus;
     int max_blocks_per_cu; // 0 = what the occupancy query allows
     int dma_aux;           // cache policy of the HBM->LDS loads: 0 default, 2 nt

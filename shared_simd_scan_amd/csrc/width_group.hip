@@ -1,5 +1,7 @@
 // width_group.hip -- instantiates the width-templated kernels for widths MI355_WLO..MI355_WHI and
 // exports one launcher per group.  Compiled 8 times (4 widths each) so the build parallelises.
+#include <atomic>
+
 #include "dispatch.hpp"
 #include "kernels.hpp"
 
@@ -16,6 +18,18 @@ template <typename K> int blocks_per_cu(K kernel)
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlockThreads, 0) != hipSuccess || nb < 1) nb = 1;
     return nb;
+}
+
+// Kernels that take their lookup tables as dynamic LDS may need more than the default 64 KiB: raise the limit once
+// per kernel AND device (the attribute is per device; a process may hold contexts on several GPUs).
+template <auto Kernel> void allow_dynamic_lds(int max_bytes, int device)
+{
+    static std::atomic<unsigned long long> done{0};
+    const unsigned long long bit = 1ull << (device & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        (void)hipFuncSetAttribute((const void *)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
+        done.fetch_or(bit, std::memory_order_release);
+    }
 }
 
 inline int cap_bpc(int bpc, const LaunchReq &r)
@@ -110,23 +124,15 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
             // (measured, tools/sweep_p.py, 2.5e8 x 9 bit: P = 16 / 32 / 64 / 128 0.21 / 0.43 / 0.72 / 1.45 ms against
             // 0.41 / 0.58 / 0.91 / 1.50 for the dword-entry kernel, which wins from P = 256: 2.80 against 3.16 ms)
             const size_t dyn = ((size_t)((P + 7) / 8) * LutGeom<C, true>::TABLE_BYTES + 15) / 16 * 16;
-            static const bool attr8 = ((void)hipFuncSetAttribute((const void *)shared_lut_kernel<C, 2, VPL, 1, true>,
-                                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                                 (int)(160 * 1024 - lut_static_lds<C, VPL>())), true);
-            (void)attr8;
+            allow_dynamic_lds<shared_lut_kernel<C, 2, VPL, 1, true>>((int)(160 * 1024 - lut_static_lds<C, VPL>()), r.device);
             hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, true>), dim3(grid_for(ntiles, lut_bpc(8), r.num_cus)),
                                dim3(kBlockThreads), dyn, r.stream, r.scan);
         } else if (lut_fits<C, VPL>(P)) { // one dword-entry lookup table per 32 keys, in dynamic LDS
             const size_t dyn = (size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES;
             const int max_dyn = (int)(160 * 1024 - lut_static_lds<C, VPL>());
-            static const bool attr = ((void)hipFuncSetAttribute((const void *)shared_wide_kernel<C, 2, VPL, 1>,
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn),
-                                      (void)hipFuncSetAttribute((const void *)shared_wide_kernel<C, 2, VPL, 0>,
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn),
-                                      (void)hipFuncSetAttribute((const void *)shared_wide_kernel<C, 18, VPL, 0>,
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn),
-                                      true);
-            (void)attr;
+            allow_dynamic_lds<shared_wide_kernel<C, 2, VPL, 1>>(max_dyn, r.device);
+            allow_dynamic_lds<shared_wide_kernel<C, 2, VPL, 0>>(max_dyn, r.device);
+            allow_dynamic_lds<shared_wide_kernel<C, 18, VPL, 0>>(max_dyn, r.device);
             const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : 2;
             const dim3 grid(grid_for(ntiles, want, r.num_cus));
             if (linear)

@@ -647,6 +647,55 @@ def test_scan_in_list(O, eng, c, P):
     assert np.array_equal(bm.cpu().numpy(), np_bitmap(expect)) and int(hits.item()) == int(expect.sum())
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fuzz_random_shapes_and_predicates(O, eng, seed):
+    """seeded random (width, row count, predicate) combinations against numpy on the decoded values: 25 columns per
+    seed; row counts cluster around tile boundaries, keys around the ends of the value range"""
+    rng = np.random.default_rng(987_000 + seed)
+    for _ in range(25):
+        c = int(rng.integers(1, 33))
+        tile = 8192 if c <= 16 else 4096
+        n = int(rng.choice([rng.integers(1, 300), tile * rng.integers(1, 6) + rng.integers(-70, 70), rng.integers(1, 70_000)]))
+        n = max(1, n)
+        vmax = (1 << c) - 1
+        vals, col = make_column(O, eng, n, c, int(rng.integers(0, 1 << 30)))
+        v = vals.astype(np.int64)
+
+        def pick():
+            cand = [0, vmax, int(vals[int(rng.integers(0, n))]), int(rng.integers(0, vmax + 1))]
+            if c < 31:  # keys outside [0, 2^c) match nothing; at c >= 31 they are not expressible as distinct int32 keys
+                cand += [vmax + 3, -1]
+            return int(cand[int(rng.integers(0, len(cand)))])
+
+        assert np.array_equal(eng.decompress(col).cpu().numpy().view(np.uint32), vals), (c, n)
+        a, b = pick(), pick()
+        for op, expect in (("==", v == a), ("!=", v != a), ("<", v < a), (">=", v >= a),
+                           ("between", (v >= a) & (v <= b)), ("not_between", ~((v >= a) & (v <= b)))):
+            bm, hits = eng.scan_where(op, a, col, b=b)
+            assert np.array_equal(bm.cpu().numpy(), np_bitmap(expect)) and int(hits.item()) == int(expect.sum()), (c, n, op, a, b)
+        key = a if a < 2 ** 31 else a - 2 ** 32
+        bm, hits = eng.scan(key, col)
+        assert np.array_equal(bm.cpu().numpy(), np_bitmap(v == a)) and int(hits.item()) == int((v == a).sum()), (c, n, a)
+        P = int(rng.choice([1, 2, 3, 4, 7, 8, 9, 17, 32, 33, 70]))
+        keys = [pick() for _ in range(P)]
+        keys32 = [k if k < 2 ** 31 else k - 2 ** 32 for k in keys]
+        layout = str(rng.choice(["per_predicate", "linear"]))
+        count = bool(rng.integers(0, 2))
+        out, hits = eng.shared_scan(keys32, col, layout=layout, hits=None if count else False)
+        nb = (n + 7) // 8
+        got = out.cpu().numpy()
+        per_key = np.stack([np_bitmap(v == k) for k in keys])  # [P, nb]
+        if layout == "per_predicate":
+            assert np.array_equal(got[:, :nb], per_key), (c, n, P, layout)
+        else:
+            assert np.array_equal(got.reshape(nb, P), per_key.T), (c, n, P, layout)
+        if count:
+            assert np.array_equal(hits.cpu().numpy(), np.array([int((v == k).sum()) for k in keys])), (c, n, P)
+        member = np.isin(v, np.array([k for k in keys if 0 <= k <= vmax], dtype=np.int64))
+        bm, hits = eng.scan_in(keys32, col)
+        assert np.array_equal(bm.cpu().numpy(), np_bitmap(member)) and int(hits.item()) == int(member.sum()), (c, n, P)
+
+
 def test_scan_can_be_captured_in_a_hip_graph(O, eng):
     """the *_dev scan entry points only enqueue work (no allocation, no sync): capture one into a HIP graph on a
     side stream and replay it"""
