@@ -135,8 +135,10 @@ MI355_API int mi355_scan_range_dev(mi355_ctx *ctx, const void *packed_dev, uint6
  * 1 <= P <= 1024.  hits (P entries) may be NULL.
  *   host, per-predicate: outputs[k] points at >= ceil(n/8) bytes for key k;
  *   host, linear:        output holds ceil(n/8)*P bytes, byte of 8-value group g and key k at g*P+k;
- *   _dev: out_dev is one device buffer; per-predicate bitmaps start at out_dev + k*stride_bytes
- *         (stride_bytes a multiple of 16, >= ceil(n/8)); linear ignores stride_bytes. */
+ *   _dev: out_dev is one 16-byte-aligned device buffer; per-predicate bitmaps start at out_dev + k*stride_bytes
+ *         (stride_bytes a multiple of 16, >= ceil(n/8)); linear ignores stride_bytes.
+ * The reference's shared scans return no counts: pass hits = NULL for exactly its work (with counts the engine
+ * may pick a different kernel; the bitmaps are the same).  "scan_nt_stores" also governs these result stores. */
 MI355_API int mi355_shared_scan_eq(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, const int32_t *keys,
                          unsigned P, uint8_t *const *outputs, uint64_t *hits);
 MI355_API int mi355_shared_scan_eq_linear(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, const int32_t *keys,
