@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--workload", choices=["scan_eq", "scan_range", "shared_scan", "decompress"], default="scan_eq")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--layout", choices=["per_predicate", "linear"], default="per_predicate",
+                    help="shared_scan output: one bitmap per key, or the reference's linear layout (byte of group g, key k at g*8+k)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --rows per GPU; strong: --rows in total, row-range sharded at 8192-row boundaries")
     ap.add_argument("--cpu-reps", type=int, default=5)
@@ -148,7 +150,9 @@ def main():
         n, total_rows = last - first, args.rows
     mask = (1 << c) - 1
     if args.column == "mod5":
-        col = eng.generate("mod", n, c, 5, first_row=first)
+        # eq / range / decompress: v = i % 5, key 3 (src/benchmark.cpp:173,:150); shared scan: v = i % 8, keys 0..7
+        # (src/benchmark.cpp:277,:205-209 -- BASELINE config 4)
+        col = eng.generate("mod", n, c, 8 if args.workload == "shared_scan" else 5, first_row=first)
         key = 3
     else:
         col = eng.generate("splitmix", n, c, 42, first_row=first)
@@ -170,9 +174,9 @@ def main():
         kname = kernel_name("scan_range", c)
     elif args.workload == "shared_scan":
         stride = (nb + 15) // 16 * 16
-        bitmap = torch.empty((8, stride), dtype=torch.uint8, device="cuda")
+        bitmap = torch.empty((8, stride) if args.layout == "per_predicate" else (nb * 8,), dtype=torch.uint8, device="cuda")
         hits = torch.zeros(8, dtype=torch.int64, device="cuda")
-        step = lambda: eng.shared_scan(keys8, col, out=bitmap, hits=hits)  # noqa: E731
+        step = lambda: eng.shared_scan(keys8, col, layout=args.layout, out=bitmap, hits=hits)  # noqa: E731
         algo_bytes = n * c / 8 + 8 * n / 8
         kname = kernel_name("shared_scan", c)
     else:
@@ -218,6 +222,12 @@ def main():
         got = int(hits.item())
         assert got == expect_hits, f"hits {got} != {expect_hits}"
 
+    if args.workload == "shared_scan" and args.column == "mod5":
+        # rows i in [first, first+n) with i % 8 == k
+        want = [(first + n - 1 - k) // 8 - (first - 1 - k) // 8 for k in range(8)]
+        got = [int(x) for x in hits.tolist()]
+        assert got == want, f"shared-scan hits {got} != {want}"
+
     gather_ms, gather_error = None, None
     if world > 1 and not args.no_gather and args.workload in ("scan_eq", "scan_range"):
         # final exchange step of the north star: per-shard bitmaps -> rank 0 (RCCL over xGMI)
@@ -251,7 +261,8 @@ def main():
             "value": value, "unit": "values/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32" if args.workload != "decompress" else "i32", "data": "synthetic",
-            "config": {"workload": f"{args.workload} {n:.0e}x{c}bit per GPU, column={args.column}, key={key}",
+            "config": {"workload": f"{args.workload} {n:.0e}x{c}bit per GPU, column={'i%8' if args.workload == 'shared_scan' and args.column == 'mod5' else args.column}, "
+                                   + (f"keys=0..7, layout={args.layout}" if args.workload == "shared_scan" else f"key={key}"),
                        "rows_per_gpu": n, "bits": c, "parallelism": f"row-range shards x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(args, kname),
