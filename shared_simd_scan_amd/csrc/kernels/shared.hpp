@@ -1,0 +1,726 @@
+// kernels/shared.hpp -- shared multi-predicate scans: compare chain, byte-entry LDS tables, dword-entry LDS tables.  Part of kernels.hpp (gfx950 only).
+#pragma once
+
+#include "scan.hpp"
+
+namespace mi355 {
+
+// ---- general shared scan: any P <= 1024 (ceil(P/8) passes of 8 keys over the lane's registers per tile),
+// per-predicate or linear output (byte of 8-value group g and key k at g*P + k,
+// src/simd_scan_shared_linear.cpp:57).  The tile's DMA is prefetched as above; results are stored pass by pass.
+template <int C, int AUX_, int VPL>
+__global__ __launch_bounds__(kBlockThreads) void shared_general_kernel(ScanArgs a)
+{
+    using G = ScanGeom<C, VPL>;
+    constexpr int NK = kMaxKeysPerPass;
+    constexpr int WORDS = G::WORDS;
+    constexpr int AUX = AUX_ & 15;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+    __shared__ uint32_t s_hits[kMaxKeys];
+    for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxKeys; k += kBlockThreads) s_hits[k] = 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t P = a.nkeys;
+    const bool keys_in_args = P <= (uint32_t)kMaxKeysPerPass;
+    const uint32_t npass = (P + kMaxKeysPerPass - 1) / kMaxKeysPerPass;
+
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+    while (tile < tc.ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t w[G::LANE_DWORDS];
+        read_lane_data<C, VPL>(lds_wave, lane, w);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint64_t next = tile + stride;
+        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        const bool full = tile < tc.nfull;
+
+        for (uint32_t pass = 0; pass < npass; pass++) {
+            uint32_t key[kMaxKeysPerPass];
+            if (keys_in_args) {
+#pragma unroll
+                for (int q = 0; q < kMaxKeysPerPass; q++) key[q] = a.key[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < kMaxKeysPerPass; q++)
+                    key[q] = __builtin_amdgcn_readfirstlane((uint32_t)a.keys_dev[pass * kMaxKeysPerPass + q]);
+            }
+            uint32_t res[NK][WORDS];
+            decode_words<C, VPL, 0, NK, kModeShared, G::LANE_DWORDS>(w, res, key);
+            uint32_t cnts[8];
+#pragma unroll
+            for (int q = 0; q < NK; q++) {
+                const uint32_t k = pass * kMaxKeysPerPass + q;
+                cnts[q] = 0;
+                if (k < P) {
+                    uint32_t cnt = 0;
+                    if (a.layout == 0) {
+                        uint8_t *dst = a.out + (uint64_t)k * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4);
+                        if (full) {
+#pragma unroll
+                            for (int j = 0; j < WORDS; j++) cnt += __builtin_popcount(res[q][j]);
+                            store_words<WORDS>(dst, res[q]);
+                        } else {
+                            cnt = tc.finish_tail(tile, res[q], dst, 1, lane);
+                        }
+                    } else if (!full) {
+                        uint8_t *dst = a.out + (tile * G::BITMAP_BYTES + (uint64_t)lane * (WORDS * 4)) * P + k;
+                        cnt = tc.finish_tail(tile, res[q], dst, P, lane);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < WORDS; j++) cnt += __builtin_popcount(res[q][j]);
+                    }
+                    cnts[q] = cnt;
+                }
+            }
+            if (a.hits) block_hits_add8(s_hits, pass * kMaxKeysPerPass, P, cnts, lane);
+            if (a.layout != 0 && full) {
+                // linear: the 8 keys of this pass are 8 consecutive bytes of every 8-value group: gather them
+                // with 4x4 byte transposes (key-major words -> group-major key bytes) and store 8 bytes per group
+                const uint32_t nk = (P - pass * 8) < 8 ? (P - pass * 8) : 8;
+                const uint64_t g0 = tile * G::BITMAP_BYTES + (uint64_t)lane * (WORDS * 4);
+#pragma unroll
+                for (int j = 0; j < WORDS; j++) {
+                    const uint32_t r0[4] = {res[0][j], res[1][j], res[2][j], res[3][j]};
+                    const uint32_t r1[4] = {res[4][j], res[5][j], res[6][j], res[7][j]};
+                    uint32_t c0[4], c1[4]; // c0[b] = bytes of keys 0..3 for group 4j+b; c1[b] = keys 4..7
+                    transpose4x4_bytes(r0, c0);
+                    transpose4x4_bytes(r1, c1);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        uint8_t *dst = a.out + (g0 + 4 * j + b) * P + pass * 8;
+                        if (nk == 8) {
+                            store8_unaligned(dst, c0[b], c1[b]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 8; q++)
+                                if ((uint32_t)q < nk) dst[q] = (uint8_t)((q < 4 ? c0[b] : c1[b]) >> (8 * (q & 3)));
+                        }
+                    }
+                }
+            }
+        }
+        tile = next;
+    }
+    if (a.hits) block_hits_flush(a, s_hits, P);
+    hits_finalize(a, P, lane);
+}
+
+// ---- shared scan through an LDS lookup table ------------------------------------------------------
+// v_cmp / v_addc_co run at HALF rate on gfx950 (4.1 cycles per wave-instruction per SIMD against 2.3 for a plain
+// VOP2 op; tools/ubench_valu.hip), so the compare chain above costs 8 keys x 2 x 4.1 = 66 cycles per value and
+// is VALU-bound at ~1.5e12 values/s whatever the occupancy.  For P predicates the LUT form does ONE LDS byte
+// lookup per value and pass of 8 keys instead: entry[v] has bit q set iff v == key[q].  Eight consecutive
+// values give eight bytes = an 8x8 bit matrix (value x key); an in-register 8x8 bit transpose (3 masked
+// shift/xor rounds on a dword pair) turns it into the eight bitmap bytes (key x value).  That is ~1.1
+// cycles per (value, key) result instead of 8.2.
+//   one table of 2^C entries per pass while that is affordable: C <= 16 for a single pass (P <= 8: 64 KiB at most, one
+//             ds_read_u8 per value), C <= 10 for the multi-pass kernel (the tables of all passes share the LDS);
+//   else      ND digit tables (single pass: 2 digits for C <= 24, 3 beyond; multi-pass: byte digits);
+//             entry_d[digit_d(v)] has bit q set iff digit_d(key[q]) == digit_d(v); the AND over the digits is exact
+//             equality.
+// The block zeroes its tables and scatters the keys into them with LDS atomic ORs (O(table/4 + P) per block).
+// Keys outside [0, 2^C) get no bit anywhere (they match nothing, as in the reference).  P <= 64 (8 passes).
+constexpr int kLutMaxPasses = kMaxKeys / 8; // as many as fit in LDS beside the tiles (checked by the launcher)
+
+struct __attribute__((packed, aligned(1))) Unaligned128 { uint32_t w[4]; };
+
+extern __shared__ __attribute__((aligned(16))) uint8_t mi355_dyn_lds[]; // lookup tables of the multi-pass LUT kernel (size set at launch)
+
+template <int C, bool MULTI> struct LutGeom {
+    // digits per value: single pass 1 / 2 / 3 for C <= 16 / 24 / 32 (tables of <= 64 KiB, 2 x 4 KiB, 3 x 2 KiB);
+    // multi-pass 1 for C <= 10, else byte digits (small tables, so that many passes fit in LDS)
+    static constexpr int ND = MULTI ? (C <= 10 ? 1 : (C + 7) / 8) : (C <= 16 ? 1 : (C <= 24 ? 2 : 3));
+    static constexpr bool SINGLE = ND == 1;
+    static constexpr int DIGIT_BITS = SINGLE ? C : (MULTI ? 8 : (C + ND - 1) / ND);
+    static constexpr int ENTRIES = 1 << DIGIT_BITS;
+    static constexpr int TABLE_BYTES = ND * ENTRIES; // per pass of 8 keys
+    // digit d of a value or key below 2^C
+    static __device__ __forceinline__ uint32_t digit(uint32_t x, int d)
+    {
+        return (d == ND - 1) ? (x >> (DIGIT_BITS * d)) : ((x >> (DIGIT_BITS * d)) & (uint32_t)(ENTRIES - 1));
+    }
+};
+
+// 8x8 bit transpose of the 64-bit matrix (hi:lo): bit (8r + c) <-> bit (8c + r)
+__device__ __forceinline__ void transpose8x8(uint32_t &lo, uint32_t &hi)
+{
+    uint32_t t;
+    t = (lo ^ (lo >> 7)) & 0x00AA00AAu;  lo ^= t ^ (t << 7);
+    t = (hi ^ (hi >> 7)) & 0x00AA00AAu;  hi ^= t ^ (t << 7);
+    t = (lo ^ (lo >> 14)) & 0x0000CCCCu; lo ^= t ^ (t << 14);
+    t = (hi ^ (hi >> 14)) & 0x0000CCCCu; hi ^= t ^ (t << 14);
+    // 64-bit round: t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0 ; x ^= t ^ (t << 28)
+    t = (lo ^ ((lo >> 28) | (hi << 4))) & 0xF0F0F0F0u;
+    lo ^= t;
+    hi ^= t >> 4;
+}
+
+template <int C, bool MULTI> __device__ __forceinline__ uint32_t lut_lookup(const uint8_t *table, uint32_t x)
+{
+    using L = LutGeom<C, MULTI>;
+    if constexpr (L::SINGLE) {
+        return table[x];
+    } else {
+        uint32_t m = table[L::digit(x, 0)];
+#pragma unroll
+        for (int d = 1; d < L::ND; d++) m &= table[d * L::ENTRIES + L::digit(x, d)];
+        return m;
+    }
+}
+
+// Y[g] = (lo, hi): byte q of the pair = bitmap byte of key q for the lane's 8-value group g;
+// x[] = the lane's values, extracted once per tile (the passes of a multi-pass scan only differ in the table)
+template <int C, int VPL, bool TAIL, bool MULTI>
+__device__ __forceinline__ void lut_groups_x(const uint32_t (&x)[VPL], const uint8_t *table, int valid, uint32_t (&Y)[VPL / 8][2])
+{
+#pragma unroll
+    for (int g = 0; g < VPL / 8; g++) {
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t m = lut_lookup<C, MULTI>(table, x[8 * g + i]);
+            if constexpr (TAIL) m = (8 * g + i < valid) ? m : 0u;
+            if (i < 4)
+                lo |= m << (8 * i);
+            else
+                hi |= m << (8 * (i - 4));
+        }
+        transpose8x8(lo, hi);
+        Y[g][0] = lo;
+        Y[g][1] = hi;
+    }
+}
+
+template <int C, int VPL, int K, int NW> __device__ __forceinline__ void extract_all(const uint32_t (&w)[NW], uint32_t (&x)[VPL])
+{
+    x[K] = extract<C, K, NW>(w);
+    if constexpr (K + 1 < VPL) extract_all<C, VPL, K + 1, NW>(w, x);
+}
+
+// per-key bitmap words of the lane: out[q][j] = bytes q of Y[4j..4j+3]
+template <int VPL> __device__ __forceinline__ void lut_gather_keys(const uint32_t (&Y)[VPL / 8][2], uint32_t (&out)[8][VPL / 32])
+{
+#pragma unroll
+    for (int j = 0; j < VPL / 32; j++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t r[4] = {Y[4 * j + 0][h], Y[4 * j + 1][h], Y[4 * j + 2][h], Y[4 * j + 3][h]};
+            uint32_t c[4];
+            transpose4x4_bytes(r, c);
+#pragma unroll
+            for (int q = 0; q < 4; q++) out[4 * h + q][j] = c[q];
+        }
+    }
+}
+
+// LAYOUT 0: per-predicate bitmaps at out + k*out_stride; 1: linear (byte of 8-value group g and key k at
+// g*P + k, src/simd_scan_shared_linear.cpp:57).  MULTI false: P <= 8, one pass, stores deferred by one tile
+// (as in scan_kernel); true: ceil(P/8) passes per tile, stored pass by pass.
+template <int C, int AUX_, int VPL, int LAYOUT, bool MULTI>
+__global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
+{
+    using G = ScanGeom<C, VPL>;
+    using L = LutGeom<C, MULTI>;
+    constexpr int WORDS = G::WORDS;
+    constexpr int GROUPS = VPL / 8;
+    constexpr int AUX = AUX_ & 15;
+    constexpr int NTS = (AUX_ & 16) ? 1 : 0; // non-temporal result stores (outputs larger than the Infinity Cache)
+    constexpr int NRES = LAYOUT == 0 ? 8 * WORDS : GROUPS * 2; // result dwords per lane, tile and pass
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lut_static[(MULTI || L::TABLE_BYTES < 16) ? 16 : L::TABLE_BYTES];
+    uint8_t *const lut = MULTI ? mi355_dyn_lds : lut_static; // MULTI: npass * TABLE_BYTES dynamic bytes
+    __shared__ uint32_t s_hits[MULTI ? kMaxKeys : 1];          // MULTI: per-block hit counters (block_hits_add8)
+    __shared__ __attribute__((aligned(16))) uint8_t stage[(LAYOUT == 1 && !MULTI) ? kWavesPerBlock : 1][(LAYOUT == 1 && !MULTI) ? GROUPS * 8 * 64 : 16];
+    if constexpr (MULTI)
+        for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxKeys; k += kBlockThreads) s_hits[k] = 0;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t P = a.nkeys;
+    const uint32_t npass = MULTI ? (P + 7) / 8 : 1;
+
+    // the tile's DMA does not depend on the tables: get it going first
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+
+    // tables: zero, then OR bit (k % 8) into the entry (or, digit tables: the ND entries) of every in-range key k
+    {
+        uint32_t *const lut32 = (uint32_t *)lut;
+        const uint32_t ndw = (npass * L::TABLE_BYTES + 3) / 4;
+        for (uint32_t i = threadIdx.x; i < ndw; i += kBlockThreads) lut32[i] = 0;
+        __syncthreads();
+        auto scatter = [&](uint32_t k, uint32_t key) {
+            const bool in_range = C == 32 || (key >> (C & 31)) == 0;
+            if (!in_range) return;
+            const uint32_t base = (k >> 3) * L::TABLE_BYTES;
+#pragma unroll
+            for (int d = 0; d < L::ND; d++) {
+                const uint32_t e = L::SINGLE ? key : L::digit(key, d);
+                const uint32_t idx = base + d * L::ENTRIES + e;
+                __hip_atomic_fetch_or(lut32 + (idx >> 2), (1u << (k & 7)) << (8 * (idx & 3)), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        if constexpr (MULTI) {
+            for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) scatter(k, (uint32_t)a.keys_dev[k]);
+        } else {
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if ((uint32_t)q < P) scatter(q, a.key[q]);
+            }
+        }
+    }
+    __syncthreads();
+
+    uint32_t hits[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) hits[q] = 0;
+
+    // full-tile store of one pass: LAYOUT 0: res = out[q][j] (q-major); LAYOUT 1: res = Y[g][0..1]
+    auto store_full = [&](uint64_t t, uint32_t pass, const uint32_t (&res)[NRES]) {
+        if constexpr (LAYOUT == 0) {
+            uint8_t *dst = a.out + (uint64_t)(pass * 8) * a.out_stride + t * G::BITMAP_BYTES + lane * (WORDS * 4);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (pass * 8 + q < P) {
+                    uint32_t v[WORDS];
+#pragma unroll
+                    for (int j = 0; j < WORDS; j++) v[j] = res[q * WORDS + j];
+                    store_words<WORDS, NTS>(dst, v);
+                }
+                dst += a.out_stride;
+            }
+        } else {
+            const uint64_t g0 = t * G::BITMAP_BYTES + (uint64_t)lane * GROUPS;
+            if (!MULTI && P == 8) {
+                // the lane's GROUPS x 8 keys are 8*GROUPS contiguous bytes, the wave's tile 64 x that: transpose
+                // through a per-wave LDS stage so every store instruction writes 1 KiB contiguous instead of
+                // 64 x 16 B at a 64-B stride
+                u32x4 *st = (u32x4 *)stage[wave];
+#pragma unroll
+                for (int g = 0; g < GROUPS; g += 2) {
+                    u32x4 v = {res[2 * g], res[2 * g + 1], res[2 * g + 2], res[2 * g + 3]};
+                    st[lane * (GROUPS / 2) + g / 2] = v;
+                }
+                u32x4 *dst = (u32x4 *)(a.out + (t * G::BITMAP_BYTES) * 8);
+#pragma unroll
+                for (int j = 0; j < GROUPS / 2; j++) {
+                    if constexpr (NTS)
+                        __builtin_nontemporal_store(st[j * 64 + lane], dst + j * 64 + lane);
+                    else
+                        dst[j * 64 + lane] = st[j * 64 + lane];
+                }
+            } else if (!MULTI && P == 4) {
+                // 4 keys: a group's row is the dword of keys 0..3; the lane's GROUPS rows are contiguous
+                u32x4 *dst = (u32x4 *)(a.out + g0 * 4);
+#pragma unroll
+                for (int g = 0; g < GROUPS; g += 4) {
+                    u32x4 v = {res[2 * g], res[2 * g + 2], res[2 * g + 4], res[2 * g + 6]};
+                    dst[g / 4] = v;
+                }
+            } else if (!MULTI && P == 2) {
+                // 2 keys: a row is 2 bytes; rows of two groups share a dword (v_perm_b32: bytes 0,1 of each source)
+                u32x4 *dst = (u32x4 *)(a.out + g0 * 2);
+#pragma unroll
+                for (int g = 0; g < GROUPS; g += 8) {
+                    u32x4 v = {__builtin_amdgcn_perm(res[2 * g + 2], res[2 * g], 0x05040100u),
+                               __builtin_amdgcn_perm(res[2 * g + 6], res[2 * g + 4], 0x05040100u),
+                               __builtin_amdgcn_perm(res[2 * g + 10], res[2 * g + 8], 0x05040100u),
+                               __builtin_amdgcn_perm(res[2 * g + 14], res[2 * g + 12], 0x05040100u)};
+                    dst[g / 8] = v;
+                }
+            } else {
+                const uint32_t nk = (P - pass * 8) < 8 ? (P - pass * 8) : 8;
+#pragma unroll
+                for (int g = 0; g < GROUPS; g++) {
+                    uint8_t *dst = a.out + (g0 + g) * P + pass * 8;
+                    if (nk == 8) {
+                        store8_unaligned(dst, res[2 * g], res[2 * g + 1]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; q++)
+                            if ((uint32_t)q < nk) dst[q] = (uint8_t)(res[2 * g + (q >> 2)] >> (8 * (q & 3)));
+                    }
+                }
+            }
+        }
+    };
+
+    uint32_t resp[NRES]; // !MULTI: results of the previous tile, not yet stored
+    uint64_t prev = ~0ull;
+
+    while (tile < tc.ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t w[G::LANE_DWORDS];
+        read_lane_data<C, VPL>(lds_wave, lane, w);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!MULTI) {
+            if (prev != ~0ull) store_full(prev, 0, resp);
+            prev = ~0ull;
+        }
+        const uint64_t next = tile + stride;
+        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        const bool full = tile < tc.nfull;
+        uint32_t xs[VPL];
+        extract_all<C, VPL, 0, G::LANE_DWORDS>(w, xs);
+
+        if constexpr (MULTI && LAYOUT == 1) {
+            // Linear layout, many keys: row g (8-value group) holds P bytes, and a lane's 8 rows are contiguous.
+            // Walk the rows in order and, inside a row, the passes in order, so every row is written start to end
+            // in one go (the pass-major order revisits each 128-B line npass times: 10x slower at P = 512).
+            if (full) {
+                const uint64_t g0 = tile * G::BITMAP_BYTES + (uint64_t)lane * GROUPS;
+#pragma unroll
+                for (int g = 0; g < GROUPS; g++) {
+                    uint8_t *row = a.out + (g0 + g) * P;
+                    uint32_t xg[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) xg[i] = xs[8 * g + i];
+                    auto pass8 = [&](uint32_t pass, uint32_t &lo, uint32_t &hi) {
+                        const uint8_t *table = lut + pass * L::TABLE_BYTES;
+                        lo = 0;
+                        hi = 0;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const uint32_t m = lut_lookup<C, MULTI>(table, xg[i]);
+                            if (i < 4)
+                                lo |= m << (8 * i);
+                            else
+                                hi |= m << (8 * (i - 4));
+                        }
+                        transpose8x8(lo, hi);
+                    };
+                    uint32_t pass = 0;
+                    // two passes = 16 keys = one 16-byte store while whole pairs remain
+                    for (; pass + 2 <= P / 8; pass += 2) {
+                        uint32_t l0, h0, l1, h1;
+                        pass8(pass, l0, h0);
+                        pass8(pass + 1, l1, h1);
+                        Unaligned128 v;
+                        v.w[0] = l0; v.w[1] = h0; v.w[2] = l1; v.w[3] = h1;
+                        *(Unaligned128 *)(row + pass * 8) = v;
+                    }
+                    for (; pass < npass; pass++) {
+                        uint32_t lo, hi;
+                        pass8(pass, lo, hi);
+                        const uint32_t nk = (P - pass * 8) < 8 ? (P - pass * 8) : 8;
+                        if (nk == 8) {
+                            store8_unaligned(row + pass * 8, lo, hi);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 8; q++)
+                                if ((uint32_t)q < nk) row[pass * 8 + q] = (uint8_t)((q < 4 ? lo : hi) >> (8 * (q & 3)));
+                        }
+                    }
+                }
+            }
+        }
+
+        // pass-major loop: per-predicate stores, hit counts, tail tiles (and everything for one-pass scans)
+        for (uint32_t pass = 0; pass < npass && (!(MULTI && LAYOUT == 1) || !full || a.hits); pass++) {
+            const uint8_t *table = lut + pass * L::TABLE_BYTES;
+            uint32_t Y[GROUPS][2];
+            uint32_t out[8][WORDS];
+            if (full) {
+                lut_groups_x<C, VPL, false, MULTI>(xs, table, VPL, Y);
+                if (LAYOUT == 0 || a.hits) lut_gather_keys<VPL>(Y, out);
+                if (a.hits) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+#pragma unroll
+                        for (int j = 0; j < WORDS; j++) hits[q] += __builtin_popcount(out[q][j]);
+                }
+                uint32_t res[NRES];
+                if constexpr (LAYOUT == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+#pragma unroll
+                        for (int j = 0; j < WORDS; j++) res[q * WORDS + j] = out[q][j];
+                } else {
+#pragma unroll
+                    for (int g = 0; g < GROUPS; g++) { res[2 * g] = Y[g][0]; res[2 * g + 1] = Y[g][1]; }
+                }
+                if constexpr (!MULTI) {
+#pragma unroll
+                    for (int i = 0; i < NRES; i++) resp[i] = res[i];
+                    prev = tile;
+                } else {
+                    if (a.hits) {
+                        block_hits_add8(s_hits, pass * 8, P, hits, lane);
+#pragma unroll
+                        for (int q = 0; q < 8; q++) hits[q] = 0;
+                    }
+                    // LAYOUT 1: the rows are written group by group below (each row's P bytes back to back)
+                    if constexpr (LAYOUT == 0) store_full(tile, pass, res);
+                }
+            } else {
+                // tail tile: lookups of values >= n are zeroed; the bitmap is written byte-exact
+                const int64_t left = (int64_t)(tc.n - tile * G::TILE_VALUES) - (int64_t)lane * VPL;
+                const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
+                const int nbytes = (valid + 7) / 8;
+                lut_groups_x<C, VPL, true, MULTI>(xs, table, valid, Y);
+                lut_gather_keys<VPL>(Y, out);
+                uint32_t tcnt[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t k = pass * 8 + q;
+                    tcnt[q] = 0;
+                    if (k < P) {
+                        uint32_t cnt = 0;
+#pragma unroll
+                        for (int j = 0; j < WORDS; j++) cnt += __builtin_popcount(out[q][j]);
+                        if constexpr (!MULTI)
+                            hits[q] += cnt;
+                        else
+                            tcnt[q] = cnt;
+                        uint8_t *dst = LAYOUT == 0
+                                           ? a.out + (uint64_t)k * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4)
+                                           : a.out + (tile * G::BITMAP_BYTES + (uint64_t)lane * GROUPS) * P + k;
+                        const uint64_t bstride = LAYOUT == 0 ? 1 : P;
+#pragma unroll
+                        for (int b = 0; b < WORDS * 4; b++)
+                            if (b < nbytes) dst[(uint64_t)b * bstride] = (uint8_t)(out[q][b >> 2] >> (8 * (b & 3)));
+                    }
+                }
+                if constexpr (MULTI) {
+                    if (a.hits) block_hits_add8(s_hits, pass * 8, P, tcnt, lane);
+                }
+            }
+        }
+        tile = next;
+    }
+    if constexpr (MULTI) {
+        if (a.hits) block_hits_flush(a, s_hits, P);
+    }
+    if constexpr (!MULTI) {
+        if (prev != ~0ull) store_full(prev, 0, resp);
+        if (a.hits) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                uint32_t s = wave_sum(hits[q]);
+                if ((uint32_t)q < P) hits_add(a, q, s, lane);
+            }
+        }
+    }
+    hits_finalize(a, P, lane);
+}
+
+// ---- shared scan, P > 8: 32 predicates per LDS lookup -----------------------------------------------
+// With byte entries a scan over P keys does P/8 lookups per value, and at P >= 32 those lookups (random
+// ds_read_u8, ~5 LDS cycles each per CU) bound the kernel at ~3.7e12 lookups/s.  Here the tables hold DWORD
+// entries -- bit (k % 32) of entry[v] of table k / 32 is set iff v == key[k] -- so one ds_read_b32 answers 32
+// predicates: the 8 dwords of an 8-value group are split into their 4 key-bytes with two 4x4 byte transposes
+// (v_perm_b32), and each key-byte's (value x key) 8x8 bit matrix is transposed as in shared_lut_kernel.
+//   C <= 10: one table of 2^C dwords per 32 keys; C > 10: ceil(C/8) byte-digit tables of 256 dwords, ANDed.
+// LAYOUT 0: per-predicate bitmaps, pass-major (a wave-store is 512 B contiguous per key).
+// LAYOUT 1: linear; every 8-value group's row of P bytes is written start to end, 32 bytes per lookup round.
+template <int C> struct WideLutGeom {
+    static constexpr int ND = C <= 10 ? 1 : (C + 7) / 8;
+    static constexpr bool SINGLE = ND == 1;
+    static constexpr int DIGIT_BITS = SINGLE ? C : 8;
+    static constexpr int ENTRIES = 1 << DIGIT_BITS;
+    static constexpr int TABLE_DWORDS = ND * ENTRIES; // per pass of 32 keys
+    static constexpr int TABLE_BYTES = TABLE_DWORDS * 4;
+    static __device__ __forceinline__ uint32_t digit(uint32_t x, int d)
+    {
+        return (d == ND - 1) ? (x >> (DIGIT_BITS * d)) : ((x >> (DIGIT_BITS * d)) & (uint32_t)(ENTRIES - 1));
+    }
+    static __device__ __forceinline__ uint32_t lookup(const uint32_t *table, uint32_t x)
+    {
+        if constexpr (SINGLE) {
+            return table[x];
+        } else {
+            uint32_t m = table[digit(x, 0)];
+#pragma unroll
+            for (int d = 1; d < ND; d++) m &= table[d * ENTRIES + digit(x, d)];
+            return m;
+        }
+    }
+};
+
+template <int C, int AUX_, int VPL, int LAYOUT>
+__global__ __launch_bounds__(kBlockThreads) void shared_wide_kernel(ScanArgs a)
+{
+    using G = ScanGeom<C, VPL>;
+    using L = WideLutGeom<C>;
+    constexpr int WORDS = G::WORDS;
+    constexpr int GROUPS = VPL / 8;
+    constexpr int AUX = AUX_ & 15;
+    constexpr int NTS = (AUX_ & 16) ? 1 : 0; // non-temporal result stores
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+    __shared__ uint32_t s_hits[kMaxKeys]; // per-block hit counters (block_hits_add8)
+    uint32_t *const lut = (uint32_t *)mi355_dyn_lds; // ceil(P/32) * TABLE_BYTES dynamic bytes
+    for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxKeys; k += kBlockThreads) s_hits[k] = 0;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t P = a.nkeys;
+    const uint32_t npass32 = (P + 31) / 32;
+
+    // the tile's DMA does not depend on the tables: get it going first
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+
+    for (uint32_t i = threadIdx.x; i < npass32 * L::TABLE_DWORDS; i += kBlockThreads) lut[i] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) {
+        const uint32_t key = (uint32_t)a.keys_dev[k];
+        const bool in_range = C == 32 || (key >> (C & 31)) == 0;
+        if (in_range) {
+#pragma unroll
+            for (int d = 0; d < L::ND; d++) {
+                const uint32_t e = L::SINGLE ? key : L::digit(key, d);
+                __hip_atomic_fetch_or(lut + (k >> 5) * L::TABLE_DWORDS + d * L::ENTRIES + e, 1u << (k & 31), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+
+    // (value x 32 keys) dwords of one 8-value group -> for each key-byte b the transposed pair: byte q of
+    // (lo, hi) = bitmap byte of key 8b + q for this group
+    // (nb = key-bytes in use, 1..4: the last table of a scan over P keys may be partly empty)
+    auto group32 = [&](const uint32_t *table, const uint32_t (&x)[VPL], int g, int valid, bool tail, uint32_t nb, uint32_t (&Y)[4][2]) {
+        uint32_t m[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            m[i] = L::lookup(table, x[8 * g + i]);
+            if (tail) m[i] = (8 * g + i < valid) ? m[i] : 0u;
+        }
+        const uint32_t r0[4] = {m[0], m[1], m[2], m[3]}, r1[4] = {m[4], m[5], m[6], m[7]};
+        uint32_t lo4[4], hi4[4];
+        transpose4x4_bytes(r0, lo4);
+        transpose4x4_bytes(r1, hi4);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint32_t lo = lo4[b], hi = hi4[b];
+            if ((uint32_t)b < nb) transpose8x8(lo, hi);
+            Y[b][0] = lo;
+            Y[b][1] = hi;
+        }
+    };
+
+    while (tile < tc.ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t w[G::LANE_DWORDS];
+        read_lane_data<C, VPL>(lds_wave, lane, w);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint64_t next = tile + stride;
+        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        const bool full = tile < tc.nfull;
+        uint32_t xs[VPL];
+        extract_all<C, VPL, 0, G::LANE_DWORDS>(w, xs);
+        const int64_t left = (int64_t)(tc.n - tile * G::TILE_VALUES) - (int64_t)lane * VPL;
+        const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
+
+        if constexpr (LAYOUT == 1) {
+            if (full) {
+                const uint64_t g0 = tile * G::BITMAP_BYTES + (uint64_t)lane * GROUPS;
+#pragma unroll
+                for (int g = 0; g < GROUPS; g++) {
+                    uint8_t *row = a.out + (g0 + g) * P;
+                    for (uint32_t p32 = 0; p32 < npass32; p32++) {
+                        uint32_t Y[4][2];
+                        const uint32_t nk = (P - p32 * 32) < 32 ? (P - p32 * 32) : 32;
+                        group32(lut + p32 * L::TABLE_DWORDS, xs, g, VPL, false, (nk + 7) / 8, Y);
+                        uint8_t *dst = row + p32 * 32;
+                        if (nk == 32) {
+                            Unaligned128 v0, v1;
+                            v0.w[0] = Y[0][0]; v0.w[1] = Y[0][1]; v0.w[2] = Y[1][0]; v0.w[3] = Y[1][1];
+                            v1.w[0] = Y[2][0]; v1.w[1] = Y[2][1]; v1.w[2] = Y[3][0]; v1.w[3] = Y[3][1];
+                            *(Unaligned128 *)dst = v0;
+                            *(Unaligned128 *)(dst + 16) = v1;
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < 4; b++) {
+                                if ((uint32_t)(8 * b + 8) <= nk) {
+                                    store8_unaligned(dst + 8 * b, Y[b][0], Y[b][1]);
+                                } else {
+#pragma unroll
+                                    for (int q = 0; q < 8; q++)
+                                        if ((uint32_t)(8 * b + q) < nk) dst[8 * b + q] = (uint8_t)(Y[b][q >> 2] >> (8 * (q & 3)));
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // pass-major: per-predicate stores, hit counts, tail tiles
+        if (LAYOUT == 0 || !full || a.hits) {
+            for (uint32_t p32 = 0; p32 < npass32; p32++) {
+                const uint32_t *table = lut + p32 * L::TABLE_DWORDS;
+                uint32_t Yb[4][GROUPS][2];
+                const uint32_t nb32 = ((P - p32 * 32) < 32 ? (P - p32 * 32) + 7 : 39) / 8;
+#pragma unroll
+                for (int g = 0; g < GROUPS; g++) {
+                    uint32_t Y[4][2];
+                    group32(table, xs, g, valid, !full, nb32, Y);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) { Yb[b][g][0] = Y[b][0]; Yb[b][g][1] = Y[b][1]; }
+                }
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t pass = p32 * 4 + b;
+                    if (pass * 8 < P) {
+                        uint32_t out[8][WORDS];
+                        lut_gather_keys<VPL>(Yb[b], out);
+                        uint32_t cnt[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            cnt[q] = 0;
+#pragma unroll
+                            for (int j = 0; j < WORDS; j++) cnt[q] += __builtin_popcount(out[q][j]);
+                        }
+                        if (a.hits) block_hits_add8(s_hits, pass * 8, P, cnt, lane);
+                        if (full) {
+                            if constexpr (LAYOUT == 0) {
+                                uint8_t *dst = a.out + (uint64_t)(pass * 8) * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4);
+#pragma unroll
+                                for (int q = 0; q < 8; q++) {
+                                    if (pass * 8 + q < P) store_words<WORDS, NTS>(dst, out[q]);
+                                    dst += a.out_stride;
+                                }
+                            }
+                        } else {
+                            // tail tile: lookups of values >= n were zeroed; the bitmap is written byte-exact
+                            const int nbytes = (valid + 7) / 8;
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                const uint32_t k = pass * 8 + q;
+                                if (k < P) {
+                                    uint8_t *dst = LAYOUT == 0
+                                                       ? a.out + (uint64_t)k * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4)
+                                                       : a.out + (tile * G::BITMAP_BYTES + (uint64_t)lane * GROUPS) * P + k;
+                                    const uint64_t bstride = LAYOUT == 0 ? 1 : P;
+#pragma unroll
+                                    for (int bb = 0; bb < WORDS * 4; bb++)
+                                        if (bb < nbytes) dst[(uint64_t)bb * bstride] = (uint8_t)(out[q][bb >> 2] >> (8 * (bb & 3)));
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        tile = next;
+    }
+    if (a.hits) block_hits_flush(a, s_hits, P);
+    hits_finalize(a, P, lane);
+}
+
+} // namespace mi355
