@@ -302,25 +302,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
             }
         } else {
             const uint64_t g0 = t * G::BITMAP_BYTES + (uint64_t)lane * GROUPS;
-            if (!MULTI && P == 8) {
-                // the lane's GROUPS x 8 keys are 8*GROUPS contiguous bytes, the wave's tile 64 x that: transpose
-                // through a per-wave LDS stage so every store instruction writes 1 KiB contiguous instead of
-                // 64 x 16 B at a 64-B stride
-                u32x4 *st = (u32x4 *)stage[wave];
-#pragma unroll
-                for (int g = 0; g < GROUPS; g += 2) {
-                    u32x4 v = {res[2 * g], res[2 * g + 1], res[2 * g + 2], res[2 * g + 3]};
-                    st[lane * (GROUPS / 2) + g / 2] = v;
-                }
-                u32x4 *dst = (u32x4 *)(a.out + (t * G::BITMAP_BYTES) * 8);
-#pragma unroll
-                for (int j = 0; j < GROUPS / 2; j++) {
-                    if constexpr (NTS)
-                        __builtin_nontemporal_store(st[j * 64 + lane], dst + j * 64 + lane);
-                    else
-                        dst[j * 64 + lane] = st[j * 64 + lane];
-                }
-            } else if (!MULTI && P == 4) {
+            if (!MULTI && P == 4) { // (8 keys: see stage_put / stage_store below)
                 // 4 keys: a group's row is the dword of keys 0..3; the lane's GROUPS rows are contiguous
                 u32x4 *dst = (u32x4 *)(a.out + g0 * 4);
 #pragma unroll
@@ -356,16 +338,53 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
         }
     };
 
-    uint32_t resp[NRES]; // !MULTI: results of the previous tile, not yet stored
+    // Linear layout, 8 keys: the lane's GROUPS x 8 result bytes are 8*GROUPS contiguous output bytes and the wave's tile
+    // 64 x that.  They are transposed through a per-wave LDS stage so that every store instruction writes 1 KiB
+    // contiguous (instead of 64 x 16 B at a 64-B stride): written to the stage as soon as they are computed, read back
+    // at the top of the next iteration together with the next tile's data (one LDS wait for both), stored, and only
+    // then is the following DMA issued -- the stage round trip never sits between a DMA wait and the next DMA issue.
+    const bool lin8 = LAYOUT == 1 && !MULTI && P == 8;
+    auto stage_put = [&](const uint32_t (&res)[NRES]) {
+        u32x4 *st = (u32x4 *)stage[wave];
+#pragma unroll
+        for (int g = 0; g < GROUPS; g += 2) {
+            u32x4 v = {res[2 * g], res[2 * g + 1], res[2 * g + 2], res[2 * g + 3]};
+            st[lane * (GROUPS / 2) + g / 2] = v;
+        }
+    };
+    auto stage_get = [&](u32x4 (&r)[GROUPS / 2]) {
+        const u32x4 *st = (const u32x4 *)stage[wave];
+#pragma unroll
+        for (int j = 0; j < GROUPS / 2; j++) r[j] = st[j * 64 + lane];
+    };
+    auto stage_store = [&](uint64_t t, const u32x4 (&r)[GROUPS / 2]) {
+        u32x4 *dst = (u32x4 *)(a.out + (t * G::BITMAP_BYTES) * 8);
+#pragma unroll
+        for (int j = 0; j < GROUPS / 2; j++) {
+            if constexpr (NTS)
+                __builtin_nontemporal_store(r[j], dst + j * 64 + lane);
+            else
+                dst[j * 64 + lane] = r[j];
+        }
+    };
+
+    uint32_t resp[NRES]; // !MULTI: results of the previous tile, not yet stored (lin8: they wait in the LDS stage)
     uint64_t prev = ~0ull;
 
     while (tile < tc.ntiles) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t w[G::LANE_DWORDS];
         read_lane_data<C, VPL>(lds_wave, lane, w);
+        u32x4 staged[GROUPS / 2];
+        if (lin8 && prev != ~0ull) stage_get(staged);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (!MULTI) {
-            if (prev != ~0ull) store_full(prev, 0, resp);
+            if (prev != ~0ull) {
+                if (lin8)
+                    stage_store(prev, staged);
+                else
+                    store_full(prev, 0, resp);
+            }
             prev = ~0ull;
         }
         const uint64_t next = tile + stride;
@@ -451,8 +470,12 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                     for (int g = 0; g < GROUPS; g++) { res[2 * g] = Y[g][0]; res[2 * g + 1] = Y[g][1]; }
                 }
                 if constexpr (!MULTI) {
+                    if (lin8) {
+                        stage_put(res);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < NRES; i++) resp[i] = res[i];
+                        for (int i = 0; i < NRES; i++) resp[i] = res[i];
+                    }
                     prev = tile;
                 } else {
                     if (a.hits) {
@@ -503,7 +526,15 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
         if (a.hits) block_hits_flush(a, s_hits, P);
     }
     if constexpr (!MULTI) {
-        if (prev != ~0ull) store_full(prev, 0, resp);
+        if (prev != ~0ull) {
+            if (lin8) {
+                u32x4 staged[GROUPS / 2];
+                stage_get(staged);
+                stage_store(prev, staged);
+            } else {
+                store_full(prev, 0, resp);
+            }
+        }
         if (a.hits) {
 #pragma unroll
             for (int q = 0; q < 8; q++) {
