@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--layout", choices=["per_predicate", "linear"], default="per_predicate",
                     help="shared_scan output: one bitmap per key, or the reference's linear layout (byte of group g, key k at g*8+k)")
+    ap.add_argument("--pipelined-gather", action="store_true",
+                    help="N>1: also time ShardedColumn.scan_pipelined (chunked scan, asynchronous gathers overlapping it)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --rows per GPU; strong: --rows in total, row-range sharded at 8192-row boundaries")
     ap.add_argument("--cpu-reps", type=int, default=5)
@@ -228,7 +230,7 @@ def main():
         got = [int(x) for x in hits.tolist()]
         assert got == want, f"shared-scan hits {got} != {want}"
 
-    gather_ms, gather_error = None, None
+    gather_ms, gather_error, pipelined_ms = None, None, None
     if world > 1 and not args.no_gather and args.workload in ("scan_eq", "scan_range"):
         # final exchange step of the north star: per-shard bitmaps -> rank 0 (RCCL over xGMI)
         from shared_simd_scan_amd.sharded import gather_bitmaps
@@ -248,6 +250,26 @@ def main():
             gather_ms = reduce_max(gather_ms)
         except Exception as e:  # the scan figures above stand on their own; report the exchange step as failed
             gather_error = f"{type(e).__name__}: {e}"
+        if args.pipelined_gather and args.workload == "scan_eq" and gather_error is None:
+            try:
+                from shared_simd_scan_amd.sharded import ShardedColumn
+
+                sc = ShardedColumn(total_rows, c, engine=eng)
+                if args.scaling == "weak":  # every rank owns exactly --rows rows
+                    sc.ranges = [(r * n, (r + 1) * n) for r in range(world)]
+                    sc.first, sc.last, sc.rows = first, first + n, n
+                sc.col = col
+                sc.scan_pipelined(key, dst=0, chunks=4)  # warm
+                sync_all()
+                g0 = time.perf_counter()
+                for _ in range(5):
+                    full_p, hits_p = sc.scan_pipelined(key, dst=0, chunks=4)
+                sync_all()
+                pipelined_ms = reduce_max((time.perf_counter() - g0) / 5 * 1e3)
+                if rank == 0:
+                    assert torch.equal(full_p, full), "pipelined gather: bitmap differs from the plain gather"
+            except Exception as e:
+                gather_error = f"pipelined: {type(e).__name__}: {e}"
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -275,6 +297,8 @@ def main():
             line["gather_ms"] = gather_ms
             line["gather_gb_per_s"] = (total_rows / 8 - nb) / (gather_ms * 1e-3) / 1e9
             line["end_to_end_values_per_s"] = total_rows / ((ms_per_step + gather_ms) * 1e-3)
+        if pipelined_ms is not None:  # one query = chunked scan with the gathers overlapping it (vs ms_per_step + gather_ms)
+            line["pipelined_scan_gather_ms"] = pipelined_ms
         if gather_error is not None:
             line["gather_error"] = gather_error
         if world == 1 and not args.no_cpu_baseline and args.workload == "scan_eq":

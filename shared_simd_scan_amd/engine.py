@@ -110,6 +110,14 @@ class ScanEngine:
             raise TypeError(f"values dtype {values.dtype}: need a 16- or 32-bit integer tensor")
         return col
 
+    def slice_rows(self, col: PackedColumn, first: int, last: int) -> PackedColumn:
+        """View of rows [first, last) of a resident column (no copy).  `first` must be a multiple of 128 rows so the
+        slice starts on a whole value, 16-byte aligned; a slice that ends inside the column is followed by the next
+        rows instead of the zero pad, which only feeds result bits >= n (masked by every kernel)."""
+        if first % 128 or not (0 <= first <= last <= col.n):
+            raise ValueError("slice_rows: first must be a multiple of 128 and 0 <= first <= last <= n")
+        return PackedColumn(col.data[first * col.c // 8:], last - first, col.c)
+
     def generate(self, kind: str, n: int, c: int, param: int = 0, first_row: int = 0) -> PackedColumn:
         """Synthesise a packed column on the device: 'mod' | 'splitmix' | 'index' (SURVEY 8d)."""
         code = {"mod": _capi.GEN_MOD, "splitmix": _capi.GEN_SPLITMIX, "index": _capi.GEN_INDEX}[kind]

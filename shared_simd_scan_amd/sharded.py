@@ -108,6 +108,71 @@ class ShardedColumn:
         bitmap, hits = self.engine.scan_range(lo, hi, self.col)
         return self._finish(bitmap, hits, dst)
 
+    def scan_pipelined(self, key: int, dst: int = 0, chunks: int = 4):
+        """Same result as scan().  The shard is scanned in `chunks` row ranges (boundaries at multiples of SHARD_ALIGN)
+        and the gather of range i is started asynchronously as soon as its scan is enqueued: with RCCL the transfer of
+        range i over xGMI runs while range i+1 is scanned (the gather, not the scan, dominates a multi-GPU
+        query).  Every rank sends `chunks` equal-sized pieces (short or empty ones are zero-padded); on the root, full
+        pieces land directly in the final bitmap."""
+        world, rank, eng = self.world, self.rank, self.engine
+        per_rank = max(b - a for a, b in self.ranges)
+        per = -(-max(per_rank, 1) // max(1, chunks))
+        per = -(-per // SHARD_ALIGN) * SHARD_ALIGN         # rows per piece, the same on every rank
+        npieces = max(1, -(-per_rank // per))
+        cb = per // 8                                       # bytes per piece
+        sizes = [bitmap_bytes(b - a) for a, b in self.ranges]
+        offs = [sum(sizes[:r]) for r in range(world)]
+        staged_via_host = None
+        final, temps, works, keep = None, [], [], []
+        hits_total = None
+        for i in range(npieces):
+            a, b = min(self.rows, i * per), min(self.rows, (i + 1) * per)
+            piece = None
+            if b > a:
+                bm, h = eng.scan(key, eng.slice_rows(self.col, a, b))
+                hits_total = h.clone() if hits_total is None else hits_total + h
+                piece = bm[: bitmap_bytes(b - a)]
+            if piece is None or piece.numel() != cb:
+                padded = torch.zeros(cb, dtype=torch.uint8, device=piece.device if piece is not None else self._device())
+                if piece is not None:
+                    padded[: piece.numel()] = piece
+                piece = padded
+            if staged_via_host is None:
+                staged_via_host = piece.is_cuda and dist.get_backend(self.group) == "gloo"
+            if staged_via_host:
+                piece = piece.cpu()  # rehearsal on a box with fewer GPUs than ranks: no overlap, same data path
+            gather_list = None
+            if rank == dst:
+                if final is None:
+                    final = torch.empty(sum(sizes), dtype=torch.uint8, device=piece.device)
+                gather_list = []
+                for r in range(world):
+                    rows_r = self.ranges[r][1] - self.ranges[r][0]
+                    valid = bitmap_bytes(max(0, min(per, rows_r - i * per)))
+                    if valid == cb:
+                        gather_list.append(final[offs[r] + i * cb: offs[r] + (i + 1) * cb])
+                    else:
+                        t = torch.empty(cb, dtype=torch.uint8, device=piece.device)
+                        temps.append((t, offs[r] + i * cb, valid))
+                        gather_list.append(t)
+            keep.append(piece)
+            works.append(dist.gather(piece, gather_list=gather_list, dst=dst, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        if hits_total is None:
+            hits_total = torch.zeros(1, dtype=torch.int64, device=self._device())
+        if rank == dst:
+            for t, off, valid in temps:
+                if valid:
+                    final[off: off + valid] = t[:valid]
+            if staged_via_host:
+                final = final.to(self._device())
+        return (final if rank == dst else None), sum_hits(hits_total, self.group)
+
+    def _device(self):
+        data = getattr(self.col, "data", None)
+        return data.device if isinstance(data, torch.Tensor) else torch.device("cpu")
+
     def _finish(self, bitmap, hits, dst):
         sizes = [bitmap_bytes(b - a) for a, b in self.ranges]
         full = gather_bitmaps(bitmap[: sizes[self.rank]], dst=dst, sizes=sizes, group=self.group)

@@ -696,6 +696,31 @@ def test_fuzz_random_shapes_and_predicates(O, eng, seed):
         assert np.array_equal(bm.cpu().numpy(), np_bitmap(member)) and int(hits.item()) == int(member.sum()), (c, n, P)
 
 
+@pytest.mark.parametrize("c", [5, 9, 12, 21])
+def test_slice_rows_scans_equal_slices_of_the_full_scan(O, eng, c):
+    """ShardedColumn.scan_pipelined scans row ranges of a resident column through views (ScanEngine.slice_rows):
+    interior slices are followed by more rows instead of the zero pad; their bitmaps must equal the matching
+    bytes of the full scan, ragged last slice included"""
+    n = 8192 * 7 + 3001
+    vals, col = make_column(O, eng, n, c, 31337 + c)
+    key = int(vals[11])
+    full, hits = eng.scan(key, col)
+    full = full.cpu().numpy()
+    total = 0
+    for a, b in ((0, 8192), (8192, 8192 * 4), (8192 * 4, 8192 * 4 + 128), (8192 * 4 + 128, n), (n - n % 128, n), (128 * 5, 128 * 5)):
+        bm, h = eng.scan(key, eng.slice_rows(col, a, b))
+        if a % 8 == 0:
+            expect = np_bitmap((vals[a:b].astype(np.int64) == key))
+            assert np.array_equal(bm.cpu().numpy()[: (b - a + 7) // 8], expect), (c, a, b)
+            if b < n and (b - a) % 8 == 0 and b > a:
+                assert np.array_equal(expect, full[a // 8: b // 8])
+        assert int(h.item()) == int((vals[a:b] == key).sum())
+        total += int(h.item()) if (a, b) in ((0, 8192), (8192, 8192 * 4), (8192 * 4, 8192 * 4 + 128), (8192 * 4 + 128, n)) else 0
+    assert total == int(hits.item())
+    with pytest.raises(ValueError):
+        eng.slice_rows(col, 100, 200)
+
+
 def test_scan_can_be_captured_in_a_hip_graph(O, eng):
     """the *_dev scan entry points only enqueue work (no allocation, no sync): capture one into a HIP graph on a
     side stream and replay it"""

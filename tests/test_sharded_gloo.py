@@ -50,6 +50,11 @@ class OracleEngine:
         vals = self.O.gen_values(kind, n, c, param, first=first_row)
         return (self.O.pack(vals, c), n, c)
 
+    def slice_rows(self, col, first, last):
+        packed, n, c = col
+        assert first % 128 == 0 and 0 <= first <= last <= n
+        return (packed[first * c // 8:], last - first, c)
+
     def scan(self, key, col):
         packed, n, c = col
         bm, hits = self.O.scan_eq(packed, n, c, key)
@@ -76,12 +81,14 @@ def worker(rank, world, port, n, c, q):
         full, hits = sc.scan(key, dst=0)
         lo, hi = (1 << c) // 4, (1 << c) // 2
         full_r, hits_r = sc.scan_range(lo, hi, dst=0)
+        full_p, hits_p = sc.scan_pipelined(key, dst=0, chunks=3)  # chunked scan + asynchronous gathers: same result
         if rank == 0:
             vals = O.gen_values("splitmix", n, c, 42)
             packed = O.pack(vals, c)
             ref, ref_hits = O.scan_eq(packed, n, c, key)
             ref_r, ref_hits_r = O.scan_range(packed, n, c, lo, hi)
             ok = (np.array_equal(full.numpy(), ref) and int(hits.item()) == ref_hits
+                  and np.array_equal(full_p.numpy(), ref) and int(hits_p.item()) == ref_hits
                   and np.array_equal(full_r.numpy(), ref_r) and int(hits_r.item()) == ref_hits_r)
             q.put(("ok" if ok else "mismatch", sc.ranges))
         else:
@@ -91,7 +98,7 @@ def worker(rank, world, port, n, c, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [100_003, 16_384, 8192 * 3 + 5, 5])
+@pytest.mark.parametrize("n", [100_003, 16_384, 8192 * 3 + 5, 5, 8192 * 9 + 1, 8192 * 8])
 def test_sharded_scan_world2_gloo(n):
     world, c = 2, 9
     ctx = mp.get_context("spawn")
