@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--layouts", default="per_predicate,linear")
     ap.add_argument("--nts", default="-1")
+    ap.add_argument("--bpc", default="0", help="max_blocks_per_cu values to sweep (0 = the engine's default)")
     args = ap.parse_args()
     import torch
 
@@ -34,8 +35,9 @@ def main():
             else:
                 out = torch.empty(nb * P, dtype=torch.uint8, device="cuda")
             hits = torch.zeros(P, dtype=torch.int64, device="cuda")
-            for nts in [int(x) for x in args.nts.split(",")]:
+            for nts, bpc in [(int(x), int(y)) for x in args.nts.split(",") for y in args.bpc.split(",")]:
                 eng.set_option("scan_nt_stores", nts)
+                eng.set_option("max_blocks_per_cu", bpc)
                 for with_hits in (True, False):
                     fn = lambda: eng.shared_scan(keys, col, layout=layout, out=out, hits=hits if with_hits else False)  # noqa: E731
                     for _ in range(2):
@@ -52,7 +54,7 @@ def main():
                     ms.sort()
                     med = ms[len(ms) // 2]
                     nbytes = n * c / 8 + n / 8 * P
-                    print(f"P={P:4d} {layout:13s} nts={nts:2d} hits={int(with_hits)}  med {med:8.4f} ms  {nbytes / med / 1e6:7.1f} GB/s  "
+                    print(f"P={P:4d} {layout:13s} nts={nts:2d} bpc={bpc} hits={int(with_hits)}  med {med:8.4f} ms  {nbytes / med / 1e6:7.1f} GB/s  "
                           f"{n * P / med * 1e3:.3e} predicate-evals/s", flush=True)
             del out
             torch.cuda.empty_cache()
