@@ -11,8 +11,11 @@
 //   one 32-bit bitmap word per 32 values in the lane, written back as 16 B / lane (1 KiB / wave).
 //
 // Kernels (one header per family under kernels/):
-//   scan_kernel            equality / range scan (+ negation, + AND with an earlier bitmap), one bitmap
-//   shared_lut_kernel      shared multi-predicate scan through an LDS lookup table + 8x8 bit transposes
+//   scan_kernel            equality / range scan (+ negation, + AND with an earlier bitmap), one bitmap; widths <= 7
+//                          evaluate several values per LDS table lookup instead of the compare chain
+//   shared_lut_kernel      shared multi-predicate scan (P <= 8, and linear rows below 192 keys) through byte-entry LDS
+//                          lookup tables + 8x8 bit transposes
+//   shared_wide_kernel     shared scan for P > 8: dword-entry tables, 32 predicates per lookup
 //   shared_general_kernel  shared scan by compare chain, for key counts whose tables do not fit in LDS
 //   in_kernel              IN-list scan (one bitmap for a key set)
 //   decompress_kernel      packed -> int32, lane per value

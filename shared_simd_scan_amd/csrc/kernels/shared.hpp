@@ -125,8 +125,8 @@ __global__ __launch_bounds__(kBlockThreads) void shared_general_kernel(ScanArgs 
 //             entry_d[digit_d(v)] has bit q set iff digit_d(key[q]) == digit_d(v); the AND over the digits is exact
 //             equality.
 // The block zeroes its tables and scatters the keys into them with LDS atomic ORs (O(table/4 + P) per block).
-// Keys outside [0, 2^C) get no bit anywhere (they match nothing, as in the reference).  P <= 64 (8 passes).
-constexpr int kLutMaxPasses = kMaxKeys / 8; // as many as fit in LDS beside the tiles (checked by the launcher)
+// Keys outside [0, 2^C) get no bit anywhere (they match nothing, as in the reference).  The multi-pass form takes as
+// many passes as its tables fit in LDS beside the tiles (checked by the launcher).
 
 struct __attribute__((packed, aligned(1))) Unaligned128 { uint32_t w[4]; };
 
