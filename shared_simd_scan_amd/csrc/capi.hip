@@ -308,12 +308,15 @@ static int pack_launch(mi355_ctx *ctx, int src, const void *values_dev, uint64_t
     unsigned grid = (unsigned)(blocks < cap ? (blocks ? blocks : 1) : cap);
     switch (src) {
 #define PACK_BY_WIDTH(SRC)                                                                                          \
-    do { /* values per output dword: at most floor(31/c) + 2 */                                                    \
-        if (c >= 16) hipLaunchKernelGGL((pack_kernel<SRC, 3>), dim3(grid), dim3(256), 0, ctx->stream, a);          \
-        else if (c >= 8) hipLaunchKernelGGL((pack_kernel<SRC, 5>), dim3(grid), dim3(256), 0, ctx->stream, a);      \
-        else if (c >= 4) hipLaunchKernelGGL((pack_kernel<SRC, 9>), dim3(grid), dim3(256), 0, ctx->stream, a);      \
-        else if (c >= 2) hipLaunchKernelGGL((pack_kernel<SRC, 17>), dim3(grid), dim3(256), 0, ctx->stream, a);     \
-        else hipLaunchKernelGGL((pack_kernel<SRC, 32>), dim3(grid), dim3(256), 0, ctx->stream, a);                 \
+    do { /* values per output dword: at most floor(31/c) + 2; one block per 8192-value tile, 4 resident per CU */  \
+        uint64_t tiles = (n + kPackTile - 1) / kPackTile;                                                           \
+        uint64_t tcap = (uint64_t)ctx->num_cus * 4;                                                                 \
+        unsigned tgrid = (unsigned)(tiles < tcap ? (tiles ? tiles : 1) : tcap);                                     \
+        if (c >= 16) hipLaunchKernelGGL((pack_tiled_kernel<SRC, 3>), dim3(tgrid), dim3(256), 0, ctx->stream, a);    \
+        else if (c >= 8) hipLaunchKernelGGL((pack_tiled_kernel<SRC, 5>), dim3(tgrid), dim3(256), 0, ctx->stream, a); \
+        else if (c >= 4) hipLaunchKernelGGL((pack_tiled_kernel<SRC, 9>), dim3(tgrid), dim3(256), 0, ctx->stream, a); \
+        else if (c >= 2) hipLaunchKernelGGL((pack_tiled_kernel<SRC, 17>), dim3(tgrid), dim3(256), 0, ctx->stream, a); \
+        else hipLaunchKernelGGL((pack_tiled_kernel<SRC, 32>), dim3(tgrid), dim3(256), 0, ctx->stream, a);           \
     } while (0)
     case kSrcU16: PACK_BY_WIDTH(kSrcU16); break;
     case kSrcU32: PACK_BY_WIDTH(kSrcU32); break;

@@ -722,6 +722,28 @@ def test_slice_rows_scans_equal_slices_of_the_full_scan(O, eng, c):
         eng.slice_rows(col, 100, 200)
 
 
+@pytest.mark.parametrize("c", [1, 7, 9, 13, 16])
+@pytest.mark.parametrize("dtype", ["u16", "u32"])
+@pytest.mark.parametrize("shift", [0, 1])
+def test_device_packer_full_tiles_and_unaligned_sources(O, eng, c, dtype, shift):
+    """the tiled packer stages 8192-value tiles through LDS with 16-byte loads when the source is 16-byte aligned and
+    falls back to element loads otherwise (shift = 1: the source starts one element into an allocation); ragged
+    last tile, u16 (the reference's compress_9bit_input type) and u32 sources"""
+    import torch
+
+    n = 3 * 8192 + 77
+    rng = np.random.default_rng(55 + c)
+    vals = rng.integers(0, 1 << c, size=n + shift, dtype=np.uint64).astype(np.uint32)
+    if dtype == "u16":
+        t = torch.from_numpy(vals.astype(np.uint16).view(np.int16)).cuda()
+    else:
+        t = torch.from_numpy(vals.view(np.int32)).cuda()
+    src = t[shift:]
+    assert (src.data_ptr() % 16 == 0) == (shift == 0)
+    col = eng.compress(src, c)
+    assert np.array_equal(col.data.cpu().numpy(), O.pack(vals[shift:], c)), (c, dtype, shift)
+
+
 def test_scan_can_be_captured_in_a_hip_graph(O, eng):
     """the *_dev scan entry points only enqueue work (no allocation, no sync): capture one into a HIP graph on a
     side stream and replay it"""
