@@ -659,13 +659,15 @@ int mi355_bitmap_to_rowids_dev(mi355_ctx *ctx, const void *bitmap_dev, uint64_t 
     g.nbytes = bitmap_bytes(n);
     g.first_row = first_row;
     g.nchunks = (g.nbytes + kRowidChunk - 1) / kRowidChunk;
-    if (ctx->rowid_ws_entries < g.nchunks + 1) {
+    const uint64_t ngroups = (g.nchunks + kRowidScanGroup - 1) / kRowidScanGroup;
+    const uint64_t ws_entries = g.nchunks + 1 + ngroups; // chunk counts, the total, one total per scan group
+    if (ctx->rowid_ws_entries < ws_entries) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->rowid_ws) HIP_TRY(hipFree(ctx->rowid_ws));
         ctx->rowid_ws = nullptr;
         ctx->rowid_ws_entries = 0;
-        HIP_TRY(hipMalloc((void **)&ctx->rowid_ws, (g.nchunks + 1) * sizeof(unsigned long long)));
-        ctx->rowid_ws_entries = g.nchunks + 1;
+        HIP_TRY(hipMalloc((void **)&ctx->rowid_ws, ws_entries * sizeof(unsigned long long)));
+        ctx->rowid_ws_entries = ws_entries;
     }
     g.chunk_counts = ctx->rowid_ws;
     g.rowids = rowids_dev;
@@ -673,7 +675,7 @@ int mi355_bitmap_to_rowids_dev(mi355_ctx *ctx, const void *bitmap_dev, uint64_t 
     uint64_t blocks = (g.nchunks + 3) / 4;
     unsigned grid = (unsigned)(blocks < (uint64_t)ctx->num_cus * 8 ? blocks : (uint64_t)ctx->num_cus * 8);
     hipLaunchKernelGGL(rowid_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, g);
-    hipLaunchKernelGGL(rowid_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, g);
+    hipLaunchKernelGGL(rowid_scan_kernel, dim3((unsigned)ngroups), dim3(256), 0, ctx->stream, g);
     hipLaunchKernelGGL(rowid_write_kernel, dim3(grid), dim3(256), 0, ctx->stream, g);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(count_dev, g.chunk_counts + g.nchunks, sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
