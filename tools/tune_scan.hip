@@ -145,6 +145,8 @@ int main(int argc, char **argv)
                   ScanGeom<C, VPL>::OCC, BYTES, (ABL) == 0 || (ABL) == 3 || (ABL) == 5})
     SCAN_VARIANT("vpl128 aux0", 128, 0, 0, scan_bytes);
     SCAN_VARIANT("vpl128 nt", 128, 2, 0, scan_bytes);
+    SCAN_VARIANT("vpl128 sc0", 128, 1, 0, scan_bytes);
+    SCAN_VARIANT("vpl128 sc0+nt", 128, 3, 0, scan_bytes);
     SCAN_VARIANT("vpl128 nt xcd-contig", 128, 2, 5, scan_bytes);
 #define SCAN_VARIANT_D2(NAME, VPL, AUX, BYTES)                                                                          \
     vs.push_back({NAME,                                                                                                \
