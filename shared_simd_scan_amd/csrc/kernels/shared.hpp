@@ -203,6 +203,79 @@ template <int C, int VPL, int K, int NW> __device__ __forceinline__ void extract
     if constexpr (K + 1 < VPL) extract_all<C, VPL, K + 1, NW>(w, x);
 }
 
+// ---- (value x key) -> (key x value) for a whole 32-value bitmap word ------------------------------------
+// R[i] byte L holds the 8-key match byte of value 8L + i of the word.  Each byte lane of the 8 registers is then an
+// 8x8 bit matrix (register x bit), and the classic three rounds of masked swaps BETWEEN registers (4 / 2 / 1 apart,
+// masks 0x0F.. / 0x33.. / 0x55..) transpose all four lanes at once: afterwards R[q] bit 8L + i = match of value
+// 8L + i against key q, i.e. R[q] IS the bitmap word of key q.  72 VOP2 ops per 32 values x 8 keys, against 4 x 30
+// for four 8x8 transposes inside register pairs plus 16 v_perm_b32 to gather the keys' bytes.
+__device__ __forceinline__ void transpose_bits_8regs(uint32_t (&R)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t t = ((R[i] >> 4) ^ R[i + 4]) & 0x0F0F0F0Fu;
+        R[i + 4] ^= t;
+        R[i] ^= t << 4;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = (k & 1) + 4 * (k >> 1); // 0, 1, 4, 5
+        const uint32_t t = ((R[i] >> 2) ^ R[i + 2]) & 0x33333333u;
+        R[i + 2] ^= t;
+        R[i] ^= t << 2;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const uint32_t t = ((R[i] >> 1) ^ R[i + 1]) & 0x55555555u;
+        R[i + 1] ^= t;
+        R[i] ^= t << 1;
+    }
+}
+
+// out[q][j] = bitmap word j of the lane for key q (one table lookup per value, byte entries); TAIL: values >= valid
+// contribute nothing
+template <int C, int VPL, bool TAIL, bool MULTI>
+__device__ __forceinline__ void lut_words(const uint32_t (&x)[VPL], const uint8_t *table, int valid, uint32_t (&out)[8][VPL / 32])
+{
+#pragma unroll
+    for (int j = 0; j < VPL / 32; j++) {
+        uint32_t R[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t r = 0;
+#pragma unroll
+            for (int L = 0; L < 4; L++) {
+                uint32_t m = lut_lookup<C, MULTI>(table, x[32 * j + 8 * L + i]);
+                if constexpr (TAIL) m = (32 * j + 8 * L + i < valid) ? m : 0u;
+                r |= m << (8 * L);
+            }
+            R[i] = r;
+        }
+        transpose_bits_8regs(R);
+#pragma unroll
+        for (int q = 0; q < 8; q++) out[q][j] = R[q];
+    }
+}
+
+// linear layout: Y[g] = (lo, hi) with byte q = bitmap byte of key q for the lane's 8-value group g = 4j + L, i.e.
+// bytes L of out[0..3][j] and of out[4..7][j]
+template <int VPL> __device__ __forceinline__ void words_to_groups(const uint32_t (&out)[8][VPL / 32], uint32_t (&Y)[VPL / 8][2])
+{
+#pragma unroll
+    for (int j = 0; j < VPL / 32; j++) {
+        const uint32_t r0[4] = {out[0][j], out[1][j], out[2][j], out[3][j]};
+        const uint32_t r1[4] = {out[4][j], out[5][j], out[6][j], out[7][j]};
+        uint32_t lo[4], hi[4];
+        transpose4x4_bytes(r0, lo);
+        transpose4x4_bytes(r1, hi);
+#pragma unroll
+        for (int L = 0; L < 4; L++) {
+            Y[4 * j + L][0] = lo[L];
+            Y[4 * j + L][1] = hi[L];
+        }
+    }
+}
+
 // per-key bitmap words of the lane: out[q][j] = bytes q of Y[4j..4j+3]
 template <int VPL> __device__ __forceinline__ void lut_gather_keys(const uint32_t (&Y)[VPL / 8][2], uint32_t (&out)[8][VPL / 32])
 {
@@ -451,8 +524,12 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
             uint32_t Y[GROUPS][2];
             uint32_t out[8][WORDS];
             if (full) {
-                lut_groups_x<C, VPL, false, MULTI>(xs, table, VPL, Y);
-                if (LAYOUT == 0 || a.hits) lut_gather_keys<VPL>(Y, out);
+                // register-wise transposition of whole bitmap words (lut_words).  Same-box A/B against the earlier
+                // per-group 8x8 transposes + byte gather, 1e9 x 9 bit, launches back to back: linear layout P = 8
+                // 0.374 against 0.394 ms (the hit counts no longer need their own gather), per-predicate P = 8 equal
+                // (0.379: the stream, not the VALU, bounds it), P = 2 0.300 against 0.338 ms.
+                lut_words<C, VPL, false, MULTI>(xs, table, VPL, out);
+                if constexpr (LAYOUT == 1) words_to_groups<VPL>(out, Y);
                 if (a.hits) {
 #pragma unroll
                     for (int q = 0; q < 8; q++)
@@ -491,8 +568,13 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                 const int64_t left = (int64_t)(tc.n - tile * G::TILE_VALUES) - (int64_t)lane * VPL;
                 const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
                 const int nbytes = (valid + 7) / 8;
-                lut_groups_x<C, VPL, true, MULTI>(xs, table, valid, Y);
-                lut_gather_keys<VPL>(Y, out);
+                if constexpr (LAYOUT == 0) { // (the per-group form here: with lut_words in this cold branch the compiler's
+                                             // schedule of the hot full-tile path came out 8 % slower)
+                    lut_groups_x<C, VPL, true, MULTI>(xs, table, valid, Y);
+                    lut_gather_keys<VPL>(Y, out);
+                } else {
+                    lut_words<C, VPL, true, MULTI>(xs, table, valid, out);
+                }
                 uint32_t tcnt[8];
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
