@@ -77,7 +77,8 @@ MI355_API int mi355_device_count(int *count);
 MI355_API int mi355_ctx_set_stream(mi355_ctx *ctx, void *hip_stream);
 /* tuning knobs: "max_blocks_per_cu" (0 = the engine's per-kernel default), "dma_aux" (bits 0-3: cache policy of
  * the HBM->LDS loads, 0 default / 2 non-temporal; bit 4: non-temporal output stores in decompress; default 18),
- * "scan_nt_stores" (bitmap stores of the equality / range scan: -1 chosen by bitmap size (default), 0 plain, 1 nt) */
+ * "scan_nt_stores" (result stores of the scans: -1 chosen by output size (default: write-through while the bitmap fits
+ * the Infinity Cache, non-temporal beyond), 0 plain, 1 non-temporal, 2 write-through) */
 MI355_API int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value);
 
 /* ---- buffer sizing, in bytes.  replaces: compressed_buffer_size / decompression_output_buffer_size

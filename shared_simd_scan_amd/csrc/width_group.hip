@@ -77,11 +77,16 @@ template <int C, int MODE> void launch_scan(const LaunchReq &r)
     // Bitmap stores: plain while the bitmap (n/8 bytes) roughly fits in the 256 MiB Infinity Cache, non-temporal beyond
     // (measured, tools/sweep.py --nts 0,1 at c = 9: 1e9 rows plain 0.196 ms / nt 0.205; 2e9 0.400 / 0.420; 3e9 0.672 /
     // 0.650; 6e9 1.318 / 1.264)
-    const bool nt_stores = r.scan_nt_stores < 0 ? r.scan.n / 8 > (300ull << 20) : r.scan_nt_stores != 0;
+    // Below that size the stores are write-through (sc1): same-box A/B with launches back to back (tools/ab_run.sh,
+    // bench.py, 1e9 x 9 bit): equality 0.2055 against 0.2091 ms with plain stores, range 0.194 against 0.207 ms --
+    // dirty bitmap lines no longer pile up in L2 to be written back under the next launch's read stream.
+    const int policy = r.scan_nt_stores < 0 ? (r.scan.n / 8 > (300ull << 20) ? 1 : 2) : r.scan_nt_stores; // 0 plain, 1 nt, 2 sc1
     if (r.dma_aux == 0)
         hipLaunchKernelGGL((scan_kernel<C, MODE, 0, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
-    else if (nt_stores)
+    else if (policy == 1)
         hipLaunchKernelGGL((scan_kernel<C, MODE, 18, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
+    else if (policy == 2)
+        hipLaunchKernelGGL((scan_kernel<C, MODE, 34, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
     else
         hipLaunchKernelGGL((scan_kernel<C, MODE, 2, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
 }

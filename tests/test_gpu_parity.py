@@ -269,7 +269,7 @@ def test_shared_scan_without_hit_counts(O, eng, c, P, layout):
     assert np.array_equal(got, oout)
 
 
-@pytest.mark.parametrize("nts", [0, 1])
+@pytest.mark.parametrize("nts", [0, 1, 2])
 @pytest.mark.parametrize("c", [7, 9, 16, 21])
 def test_store_policy_variants_agree(O, eng, c, nts):
     """the launcher picks plain or non-temporal result stores by output size (option scan_nt_stores: -1 auto);
