@@ -40,6 +40,8 @@ def parse():
                     help="shared_scan output: one bitmap per key, or the reference's linear layout (byte of group g, key k at g*8+k)")
     ap.add_argument("--pipelined-gather", action="store_true",
                     help="N>1: also time ShardedColumn.scan_pipelined (chunked scan, asynchronous gathers overlapping it)")
+    ap.add_argument("--store-policy", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="result stores of the scans: -1 engine default, 0 plain, 1 non-temporal, 2 write-through (tuning)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --rows per GPU; strong: --rows in total, row-range sharded at 8192-row boundaries")
     ap.add_argument("--cpu-reps", type=int, default=5)
@@ -142,6 +144,8 @@ def main():
     from shared_simd_scan_amd import ScanEngine, kernel_name
 
     eng = ScanEngine(local_rank)
+    if args.store_policy >= 0:
+        eng.set_option("scan_nt_stores", args.store_policy)
     n, c = args.rows, args.bits
     first = rank * n
     total_rows = world * n

@@ -376,7 +376,9 @@ template <int WORDS, int NT = 0> __device__ __forceinline__ void store_words(uin
         } else if constexpr (NT == 1) __builtin_nontemporal_store(t, (u32x4 *)dst); else *(u32x4 *)dst = t;
     } else if constexpr (WORDS == 2) {
         u32x2 t = {v[0], v[1]};
-        if constexpr (NT) __builtin_nontemporal_store(t, (u32x2 *)dst); else *(u32x2 *)dst = t;
+        if constexpr (NT == 2) {
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(t) : "memory");
+        } else if constexpr (NT == 1) __builtin_nontemporal_store(t, (u32x2 *)dst); else *(u32x2 *)dst = t;
     } else {
         if constexpr (NT) __builtin_nontemporal_store(v[0], (uint32_t *)dst); else *(uint32_t *)dst = v[0];
     }

@@ -74,13 +74,12 @@ template <int C, int MODE> void launch_scan(const LaunchReq &r)
     const uint64_t ntiles = (r.scan.n + G::TILE_VALUES - 1) / G::TILE_VALUES;
     const unsigned grid = grid_for(ntiles, scan_bpc(bpc, G::TILE_BYTES, r), r.num_cus);
     // dma_aux: cache policy of the HBM->LDS stream; 2 (non-temporal: the column is read once) is the default.
-    // Bitmap stores: plain while the bitmap (n/8 bytes) roughly fits in the 256 MiB Infinity Cache, non-temporal beyond
-    // (measured, tools/sweep.py --nts 0,1 at c = 9: 1e9 rows plain 0.196 ms / nt 0.205; 2e9 0.400 / 0.420; 3e9 0.672 /
-    // 0.650; 6e9 1.318 / 1.264)
-    // Below that size the stores are write-through (sc1): same-box A/B with launches back to back (tools/ab_run.sh,
-    // bench.py, 1e9 x 9 bit): equality 0.2055 against 0.2091 ms with plain stores, range 0.194 against 0.207 ms --
-    // dirty bitmap lines no longer pile up in L2 to be written back under the next launch's read stream.
-    const int policy = r.scan_nt_stores < 0 ? (r.scan.n / 8 > (300ull << 20) ? 1 : 2) : r.scan_nt_stores; // 0 plain, 1 nt, 2 sc1
+    // Bitmap stores, measured with launches back to back (bench.py --store-policy, same box, 1e9 x 9 bit unless noted):
+    // write-through (sc1) 0.201 ms, plain 0.207, non-temporal 0.216 -- dirty bitmap lines do not pile up in L2 to be
+    // written back under the next launch's read stream; c = 21: 0.438 / 0.467 / 0.457; c = 5: 0.127 / 0.129 / 0.136.
+    // Bitmaps far beyond the 256 MiB Infinity Cache prefer non-temporal stores: 4e9 rows sc1 0.82 ms / nt 0.85,
+    // 8e9 rows (1 GB of bitmap) 1.74 / 1.72.
+    const int policy = r.scan_nt_stores < 0 ? (r.scan.n / 8 > (768ull << 20) ? 1 : 2) : r.scan_nt_stores; // 0 plain, 1 nt, 2 sc1
     if (r.dma_aux == 0)
         hipLaunchKernelGGL((scan_kernel<C, MODE, 0, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
     else if (policy == 1)
@@ -169,8 +168,11 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
     case kOpDecompress: {
         static const int bpc = blocks_per_cu(decompress_kernel<C, 18>);
         const uint64_t ntiles = (r.decomp.n + DecompGeom<C>::TILE_VALUES - 1) / DecompGeom<C>::TILE_VALUES;
-        // measured (tools/sweep.py, tools/ceilings.hip; 1e9 rows, c = 8..21): one block per CU is 2-4 % faster than 2..8
-        const unsigned grid = grid_for(ntiles, r.max_blocks_per_cu > 0 ? cap_bpc(bpc, r) : 1, r.num_cus);
+        // measured with launches back to back (bench.py, 1e9 rows): four blocks per CU 0.863-0.871 ms at c = 9 against
+        // 0.903-0.907 with one (c = 17: 1.01 against 1.10).  Timed one launch at a time it is the other way round by
+        // 2-4 % (the write-back of the tail falls outside the kernel); sustained throughput is what counts.
+        const int want = bpc < 4 ? bpc : 4;
+        const unsigned grid = grid_for(ntiles, r.max_blocks_per_cu > 0 ? cap_bpc(bpc, r) : want, r.num_cus);
         if (r.dma_aux == 0)
             hipLaunchKernelGGL((decompress_kernel<C, 0>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);
         else if (r.dma_aux == 2) // nt DMA loads only (tools/sweep.py --aux 2)
