@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kBlockThreads) void decompress_kernel(DecompArgs a)
 {
     using G = DecompGeom<C>;
     constexpr int AUX = AUX_ & 15;          // cache policy of the DMA loads
-    constexpr bool NTS = (AUX_ & 16) != 0;  // non-temporal stores of the int32 output
+    constexpr int NTS = (AUX_ & 32) ? 2 : ((AUX_ & 16) ? 1 : 0); // stores of the int32 output: 1 non-temporal, 2 write-through (sc1)
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -76,7 +76,12 @@ __global__ __launch_bounds__(kBlockThreads) void decompress_kernel(DecompArgs a)
                     uint32_t hi = lds32[s * 8 * C + didx[j] + 1];
                     v[j] = __builtin_amdgcn_alignbit(hi, lo, sh[j]) & mask;
                 }
-                if constexpr (NTS) __builtin_nontemporal_store(v, (u32x4 *)(dst + s * 256)); else *(u32x4 *)(dst + s * 256) = v;
+                if constexpr (NTS == 2)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + s * 256), "v"(v) : "memory");
+                else if constexpr (NTS == 1)
+                    __builtin_nontemporal_store(v, (u32x4 *)(dst + s * 256));
+                else
+                    *(u32x4 *)(dst + s * 256) = v;
             }
         } else {
             const uint64_t base = tile * G::TILE_VALUES;

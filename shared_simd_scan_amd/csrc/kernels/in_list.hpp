@@ -16,6 +16,7 @@ __global__ __launch_bounds__(kBlockThreads) void in_kernel(ScanArgs a)
     using G = ScanGeom<C, VPL>;
     constexpr int WORDS = G::WORDS;
     constexpr int AUX = AUX_ & 15;
+    constexpr int NTS = (AUX_ & 32) ? 2 : ((AUX_ & 16) ? 1 : 0); // bitmap stores: 1 non-temporal, 2 write-through (sc1)
     constexpr bool BITSET = C <= 16;
     constexpr int SET_BYTES = BITSET ? ((1 << (C < 16 ? C : 16)) + 7) / 8 : 16;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(kBlockThreads) void in_kernel(ScanArgs a)
         uint32_t w[G::LANE_DWORDS];
         read_lane_data<C, VPL>(lds_wave, lane, w);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (prev != ~0ull) store_words<WORDS>(out_lane + prev * G::BITMAP_BYTES, res);
+        if (prev != ~0ull) store_words<WORDS, NTS>(out_lane + prev * G::BITMAP_BYTES, res);
         const uint64_t next = tile + stride;
         if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kBlockThreads) void in_kernel(ScanArgs a)
         }
         tile = next;
     }
-    if (prev != ~0ull) store_words<WORDS>(out_lane + prev * G::BITMAP_BYTES, res);
+    if (prev != ~0ull) store_words<WORDS, NTS>(out_lane + prev * G::BITMAP_BYTES, res);
     if (a.hits) hits_add(a, 0, wave_sum(hits), lane);
     hits_finalize(a, 1, lane);
 }

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
     constexpr int WORDS = G::WORDS;
     constexpr int GROUPS = VPL / 8;
     constexpr int AUX = AUX_ & 15;
-    constexpr int NTS = (AUX_ & 16) ? 1 : 0; // non-temporal result stores (outputs larger than the Infinity Cache)
+    constexpr int NTS = (AUX_ & 32) ? 2 : ((AUX_ & 16) ? 1 : 0); // result stores: 1 non-temporal, 2 write-through (sc1)
     constexpr int NRES = LAYOUT == 0 ? 8 * WORDS : GROUPS * 2; // result dwords per lane, tile and pass
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t lut_static[(MULTI || L::TABLE_BYTES < 16) ? 16 : L::TABLE_BYTES];
@@ -434,7 +434,9 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
         u32x4 *dst = (u32x4 *)(a.out + (t * G::BITMAP_BYTES) * 8);
 #pragma unroll
         for (int j = 0; j < GROUPS / 2; j++) {
-            if constexpr (NTS)
+            if constexpr (NTS == 2)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + j * 64 + lane), "v"(r[j]) : "memory");
+            else if constexpr (NTS == 1)
                 __builtin_nontemporal_store(r[j], dst + j * 64 + lane);
             else
                 dst[j * 64 + lane] = r[j];
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide_kernel(ScanArgs a)
     constexpr int WORDS = G::WORDS;
     constexpr int GROUPS = VPL / 8;
     constexpr int AUX = AUX_ & 15;
-    constexpr int NTS = (AUX_ & 16) ? 1 : 0; // non-temporal result stores
+    constexpr int NTS = (AUX_ & 32) ? 2 : ((AUX_ & 16) ? 1 : 0); // result stores: 1 non-temporal, 2 write-through (sc1)
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
     __shared__ uint32_t s_hits[kMaxKeys]; // per-block hit counters (block_hits_add8)
     uint32_t *const lut = (uint32_t *)mi355_dyn_lds; // ceil(P/32) * TABLE_BYTES dynamic bytes

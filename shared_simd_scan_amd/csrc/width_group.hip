@@ -115,12 +115,19 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
             static const int bpc_lin = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 1, false>);
             static const int bpc_pp = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 0, false>);
             const dim3 grid(grid_for(ntiles, lut_bpc(linear ? bpc_lin : bpc_pp), r.num_cus));
-            if (linear && nt_stores)
+            // one pass: write-through below 768 MiB of output, non-temporal beyond, as in launch_scan (launches back to
+            // back, P = 8: 1e8 rows sc1 0.046 ms / plain 0.047 / nt 0.049; 1e9 rows nt 0.353-0.383 / sc1 0.347-0.393 / plain 0.40)
+            const int spol = r.scan_nt_stores < 0 ? ((r.scan.n / 8) * P > (768ull << 20) ? 1 : 2) : r.scan_nt_stores; // 0 plain, 1 nt, 2 sc1
+            if (linear && spol == 1)
                 hipLaunchKernelGGL((shared_lut_kernel<C, 18, VPL, 1, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+            else if (linear && spol == 2)
+                hipLaunchKernelGGL((shared_lut_kernel<C, 34, VPL, 1, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
             else if (linear)
                 hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
-            else if (nt_stores)
+            else if (spol == 1)
                 hipLaunchKernelGGL((shared_lut_kernel<C, 18, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+            else if (spol == 2)
+                hipLaunchKernelGGL((shared_lut_kernel<C, 34, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
             else
                 hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
         } else if (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) {
@@ -161,8 +168,13 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         // c = 9 0.31 -> 0.23 ms, c = 12 0.32 -> 0.29, c = 16 0.51 -> 0.45 with two blocks per CU instead of one)
         int want = scan_bpc(bpc, G::TILE_BYTES, r);
         if (r.max_blocks_per_cu <= 0 && want < 2 && bpc >= 2) want = 2;
-        hipLaunchKernelGGL((in_kernel<C, 2, VPL>), dim3(grid_for(ntiles, want, r.num_cus)), dim3(kBlockThreads), 0,
-                           r.stream, r.scan);
+        const int ipol = r.scan_nt_stores < 0 ? (r.scan.n / 8 > (768ull << 20) ? 1 : 2) : r.scan_nt_stores; // as in launch_scan
+        if (ipol == 2)
+            hipLaunchKernelGGL((in_kernel<C, 34, VPL>), dim3(grid_for(ntiles, want, r.num_cus)), dim3(kBlockThreads), 0, r.stream, r.scan);
+        else if (ipol == 1)
+            hipLaunchKernelGGL((in_kernel<C, 18, VPL>), dim3(grid_for(ntiles, want, r.num_cus)), dim3(kBlockThreads), 0, r.stream, r.scan);
+        else
+            hipLaunchKernelGGL((in_kernel<C, 2, VPL>), dim3(grid_for(ntiles, want, r.num_cus)), dim3(kBlockThreads), 0, r.stream, r.scan);
         break;
     }
     case kOpDecompress: {
@@ -177,6 +189,8 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
             hipLaunchKernelGGL((decompress_kernel<C, 0>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);
         else if (r.dma_aux == 2) // nt DMA loads only (tools/sweep.py --aux 2)
             hipLaunchKernelGGL((decompress_kernel<C, 2>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);
+        else if (r.dma_aux == 34) // nt loads + write-through stores
+            hipLaunchKernelGGL((decompress_kernel<C, 34>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);
         else // default (dma_aux 18): nt loads + nt stores -- the 4 B/value output is written once (+1-2 %)
             hipLaunchKernelGGL((decompress_kernel<C, 18>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);
         break;
