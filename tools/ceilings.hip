@@ -28,7 +28,7 @@ using namespace mi355;
         }                                                                                         \
     } while (0)
 
-// one wave-step: R x 1 KiB read (nt), W x 1 KiB written (NTS: nt stores); steps strided over the persistent grid
+// one wave-step: R x 1 KiB read (nt), W x 1 KiB written (NTS: 1 nt stores, 2 write-through sc1 stores); steps strided over the persistent grid
 template <int R, int W, int NTS> __global__ __launch_bounds__(256) void mix_kernel(const u32x4 *src, u32x4 *dst, uint64_t nsteps)
 {
     const int lane = threadIdx.x & 63;
@@ -44,7 +44,9 @@ template <int R, int W, int NTS> __global__ __launch_bounds__(256) void mix_kern
         for (int w = 0; w < W; w++) {
             u32x4 v = acc;
             v.x += w;
-            if (NTS)
+            if (NTS == 2)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q + w * 64), "v"(v) : "memory");
+            else if (NTS == 1)
                 __builtin_nontemporal_store(v, q + w * 64);
             else
                 q[w * 64] = v;
@@ -114,8 +116,11 @@ int main(int argc, char **argv)
         constexpr int VPL = scan_vpl(C, kModeEq);
         using G = ScanGeom<C, VPL>;
         const uint64_t ntiles = (n + G::TILE_VALUES - 1) / G::TILE_VALUES;
-        vs.push_back({"scan_eq (product)", [=](int bpc, hipStream_t s) {
+        vs.push_back({"scan_eq (product, plain st)", [=](int bpc, hipStream_t s) {
                           hipLaunchKernelGGL((scan_kernel<C, kModeEq, 2, VPL>), dim3(grid_of(ntiles, bpc)), dim3(kBlockThreads), 0, s, sa);
+                      }, {1, 2}, read_bytes + n / 8.0});
+        vs.push_back({"scan_eq (product, sc1 st)", [=](int bpc, hipStream_t s) {
+                          hipLaunchKernelGGL((scan_kernel<C, kModeEq, 34, VPL>), dim3(grid_of(ntiles, bpc)), dim3(kBlockThreads), 0, s, sa);
                       }, {1, 2}, read_bytes + n / 8.0});
     }
     {
@@ -125,14 +130,17 @@ int main(int argc, char **argv)
         ScanArgs sr = sa;
         sr.key[0] = (1u << C) / 4;                          // lo
         sr.key[1] = (uint32_t)((1ull << C) / 2 - (1u << C) / 4); // hi - lo   (BASELINE config 3: [2^c/4, 2^c/2])
-        vs.push_back({"scan_range (product)", [=](int bpc, hipStream_t s) {
-                          hipLaunchKernelGGL((scan_kernel<C, kModeRange, 2, VPL>), dim3(grid_of(ntiles, bpc)), dim3(kBlockThreads), 0, s, sr);
+        vs.push_back({"scan_range (product, sc1 st)", [=](int bpc, hipStream_t s) {
+                          hipLaunchKernelGGL((scan_kernel<C, kModeRange, 34, VPL>), dim3(grid_of(ntiles, bpc)), dim3(kBlockThreads), 0, s, sr);
                       }, {1, 2}, read_bytes + n / 8.0});
     }
     {
         const uint64_t nsteps = (uint64_t)(read_bytes / (C * 1024));
         vs.push_back({"mix C:1", [=](int bpc, hipStream_t s) {
                           hipLaunchKernelGGL((mix_kernel<C, 1, 0>), dim3(bpc * cus), dim3(256), 0, s, (const u32x4 *)packed, (u32x4 *)out, nsteps);
+                      }, {1, 2, 4}, nsteps * 1024.0 * (C + 1)});
+        vs.push_back({"mix C:1 sc1 stores", [=](int bpc, hipStream_t s) {
+                          hipLaunchKernelGGL((mix_kernel<C, 1, 2>), dim3(bpc * cus), dim3(256), 0, s, (const u32x4 *)packed, (u32x4 *)out, nsteps);
                       }, {1, 2, 4}, nsteps * 1024.0 * (C + 1)});
     }
     {
