@@ -103,8 +103,11 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         const bool linear = r.scan.layout != 0;
         // measured (tools/tune_scan.hip, 1e9 x 9 bit, P = 8): one block per CU 0.41 ms, two 0.46, three 0.49
         // (tools/sweep.py: c = 5, 2.5 KiB tiles, is the exception -- two blocks 0.30 ms against 0.37)
+        // The linear layout (word-wise transposition + LDS row stage) wants a second block per CU on random data:
+        // launches back to back, 1e9 x 9 bit, P = 8, random column 0.36-0.37 ms against 0.417 with one block; equal on
+        // the i % 8 column; per-predicate prefers one (0.35-0.38 against 0.37-0.40).
         auto lut_bpc = [&](int occ) {
-            const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : (G::TILE_BYTES < 4096 ? 2 : 1);
+            const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : ((G::TILE_BYTES < 4096 || linear) ? 2 : 1);
             return want < occ ? want : occ;
         };
         // result stores: non-temporal unless the P bitmaps together are small.  Measured (tools/sweep.py --nts 0,1, P = 8,

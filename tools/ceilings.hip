@@ -146,8 +146,13 @@ int main(int argc, char **argv)
     {
         using G = ScanGeom<C, 64>;
         const uint64_t ntiles = (n + G::TILE_VALUES - 1) / G::TILE_VALUES;
-        vs.push_back({"shared_scan P=8 (product)", [=](int bpc, hipStream_t s) {
-                          hipLaunchKernelGGL((shared_lut_kernel<C, 2, 64, 0, false>), dim3(grid_of(ntiles, bpc)), dim3(kBlockThreads), 0, s, sh);
+        vs.push_back({"shared_scan P=8 (product, nt st)", [=](int bpc, hipStream_t s) {
+                          hipLaunchKernelGGL((shared_lut_kernel<C, 18, 64, 0, false>), dim3(grid_of(ntiles, bpc)), dim3(kBlockThreads), 0, s, sh);
+                      }, {1, 2}, read_bytes + n});
+        ScanArgs shl = sh;
+        shl.layout = 1;
+        vs.push_back({"shared_scan P=8 linear (nt st)", [=](int bpc, hipStream_t s) {
+                          hipLaunchKernelGGL((shared_lut_kernel<C, 18, 64, 1, false>), dim3(grid_of(ntiles, bpc)), dim3(kBlockThreads), 0, s, shl);
                       }, {1, 2}, read_bytes + n});
     }
     {
