@@ -72,7 +72,8 @@ MI355_API int mi355_ctx_synchronize(mi355_ctx *ctx);
 MI355_API int mi355_device_count(int *count);
 /* re-point the context at another HIP stream (e.g. a capture stream: the *_dev scan / decompress / bitmap entry
  * points enqueue work only -- no allocation, no synchronisation -- so they can be captured into a hipGraph;
- * exceptions: mi355_shared_scan_eq_dev / mi355_scan_in_dev with P > 8 synchronise to upload the key list, and
+ * exceptions: mi355_shared_scan_eq_dev / mi355_scan_in_dev with P > 8 upload the key list per call (asynchronously,
+ * through a ring of pinned slots: no stream synchronisation, but refused while the stream is capturing), and
  * mi355_bitmap_to_rowids_dev may grow its workspace) */
 MI355_API int mi355_ctx_set_stream(mi355_ctx *ctx, void *hip_stream);
 /* tuning knobs: "max_blocks_per_cu" (0 = the engine's per-kernel default), "dma_aux" (bits 0-3: cache policy of

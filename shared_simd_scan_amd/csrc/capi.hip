@@ -30,7 +30,14 @@ struct mi355_ctx {
                       // bit 4: non-temporal stores in decompress
     unsigned long long *hits_scratch = nullptr; // host-pointer API: where the kernels deliver hit counts
     unsigned long long *kernel_scratch = nullptr; // kScratchWords words, all zero between launches (kernels.hpp hits_finalize)
-    int32_t *keys_scratch = nullptr;            // 1024 + 8 keys
+    // key lists longer than 8 travel through device memory: a ring of kKeySlots pinned host slots and device slots of
+    // 1024 + 8 keys each, so uploading a list never waits for the stream (only for the copy that used the slot
+    // kKeySlots calls ago)
+    int32_t *keys_scratch = nullptr;            // device: kKeySlots x (1024 + 8) keys
+    int32_t *keys_pinned = nullptr;             // host (pinned): the same
+    hipEvent_t key_events[8] = {};
+    bool key_used[8] = {};
+    int key_next = 0;
     unsigned long long *rowid_ws = nullptr;     // chunk counts of mi355_bitmap_to_rowids_dev
     size_t rowid_ws_entries = 0;
 };
@@ -108,6 +115,30 @@ int launch(mi355_ctx *ctx, LaunchReq &r)
     return MI355_OK;
 }
 
+constexpr int kKeySlots = 8;
+constexpr size_t kKeySlotInts = kMaxKeys + 8;
+
+// P > 8 keys -> device memory (padded to a multiple of 8 with copies of the last key), asynchronously on the stream
+int upload_keys(mi355_ctx *ctx, const int32_t *keys_host, unsigned P, const int32_t **keys_dev)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(MI355_E_INVALID, "key lists longer than 8 are uploaded per call and cannot be captured into a graph");
+    const int slot = ctx->key_next;
+    ctx->key_next = (slot + 1) % kKeySlots;
+    if (ctx->key_used[slot]) HIP_TRY(hipEventSynchronize(ctx->key_events[slot])); // the copy out of this slot is done
+    int32_t *h = ctx->keys_pinned + (size_t)slot * kKeySlotInts;
+    int32_t *d = ctx->keys_scratch + (size_t)slot * kKeySlotInts;
+    const unsigned npad = (P + 7) / 8 * 8;
+    memcpy(h, keys_host, P * sizeof(int32_t));
+    for (unsigned k = P; k < npad; k++) h[k] = keys_host[P - 1];
+    HIP_TRY(hipMemcpyAsync(d, h, npad * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->key_events[slot], ctx->stream));
+    ctx->key_used[slot] = true;
+    *keys_dev = d;
+    return MI355_OK;
+}
+
 struct DevBuf { // RAII for the host-pointer (copying) entry points
     void *p = nullptr;
     ~DevBuf()
@@ -160,11 +191,16 @@ int mi355_ctx_create(int device, void *hip_stream, mi355_ctx **out)
     hipError_t e = hipMalloc((void **)&c->hits_scratch, kMaxKeys * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&c->kernel_scratch, kScratchWords * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->kernel_scratch, 0, kScratchWords * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->keys_scratch, (kMaxKeys + 8) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->keys_scratch, 8 * (kMaxKeys + 8) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->keys_pinned, 8 * (kMaxKeys + 8) * sizeof(int32_t), hipHostMallocDefault);
+    for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->key_events[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         (void)hipFree(c->hits_scratch); // hipFree(nullptr) is a no-op
         (void)hipFree(c->kernel_scratch);
         (void)hipFree(c->keys_scratch);
+        if (c->keys_pinned) (void)hipHostFree(c->keys_pinned);
+        for (int i = 0; i < 8; i++)
+            if (c->key_events[i]) (void)hipEventDestroy(c->key_events[i]);
         delete c;
         return fail(MI355_E_HIP, "hipMalloc(scratch): %s", hipGetErrorString(e));
     }
@@ -180,6 +216,9 @@ int mi355_ctx_destroy(mi355_ctx *ctx)
     (void)hipFree(ctx->hits_scratch);
     (void)hipFree(ctx->kernel_scratch);
     (void)hipFree(ctx->keys_scratch);
+    if (ctx->keys_pinned) (void)hipHostFree(ctx->keys_pinned);
+    for (int i = 0; i < 8; i++)
+        if (ctx->key_events[i]) (void)hipEventDestroy(ctx->key_events[i]);
     (void)hipFree(ctx->rowid_ws);
     {
         std::lock_guard<std::mutex> lk(g_default_mu);
@@ -488,14 +527,8 @@ int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n,
     if (P <= (unsigned)kMaxKeysPerPass) {
         for (unsigned q = 0; q < (unsigned)kMaxKeysPerPass; q++) r.scan.key[q] = (uint32_t)keys_host[q < P ? q : P - 1];
     } else {
-        // (a copy through pageable host memory: hipMemcpyAsync + sync costs ~20 us, paid only for P > 8)
-        // keys travel through device memory, padded to a multiple of 8 with copies of the last key
-        std::vector<int32_t> padded((P + 7) / 8 * 8, keys_host[P - 1]);
-        memcpy(padded.data(), keys_host, P * sizeof(int32_t));
-        HIP_TRY(hipMemcpyAsync(ctx->keys_scratch, padded.data(), padded.size() * sizeof(int32_t), hipMemcpyHostToDevice,
-                               ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream)); // `padded` dies at scope exit
-        r.scan.keys_dev = ctx->keys_scratch;
+        if ((rc = bind(ctx))) return rc;
+        if ((rc = upload_keys(ctx, keys_host, P, &r.scan.keys_dev))) return rc;
     }
     return launch(ctx, r);
 }
@@ -573,10 +606,8 @@ int mi355_scan_in_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsign
     if (((uintptr_t)packed_dev & 15) || ((uintptr_t)bitmap_dev & 15) || ((uintptr_t)and_mask_dev & 15))
         return fail(MI355_E_INVALID, "packed_dev, bitmap_dev and and_mask_dev must be 16-byte aligned");
     if ((rc = bind(ctx))) return rc;
-    std::vector<int32_t> padded((P + 7) / 8 * 8, keys_host[P - 1]);
-    memcpy(padded.data(), keys_host, P * sizeof(int32_t));
-    HIP_TRY(hipMemcpyAsync(ctx->keys_scratch, padded.data(), padded.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream)); // `padded` dies at scope exit
+    const int32_t *keys_dev = nullptr;
+    if ((rc = upload_keys(ctx, keys_host, P, &keys_dev))) return rc;
     LaunchReq r{};
     r.op = kOpScanIn;
     r.c = c;
@@ -584,7 +615,7 @@ int mi355_scan_in_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsign
     r.scan.n = n;
     r.scan.out = (uint8_t *)bitmap_dev;
     r.scan.hits = (unsigned long long *)hits_dev;
-    r.scan.keys_dev = ctx->keys_scratch;
+    r.scan.keys_dev = keys_dev;
     r.scan.nkeys = P;
     r.scan.and_mask = (const uint8_t *)and_mask_dev;
     r.scan.invert = negate ? 0xffffffffu : 0u;

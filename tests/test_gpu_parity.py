@@ -744,6 +744,38 @@ def test_device_packer_full_tiles_and_unaligned_sources(O, eng, c, dtype, shift)
     assert np.array_equal(col.data.cpu().numpy(), O.pack(vals[shift:], c)), (c, dtype, shift)
 
 
+def test_many_key_lists_in_flight_without_synchronising(O, eng):
+    """P > 8 key lists are uploaded asynchronously through a ring of 8 pinned slots: 40 shared scans / IN-list scans
+    with DIFFERENT key lists are enqueued back to back (no host synchronisation in between) and checked afterwards --
+    a slot reused too early would hand a scan another call's keys"""
+    import torch
+
+    n, c = 8192 * 3 + 333, 9
+    vals, col = make_column(O, eng, n, c, 2468)
+    v = vals.astype(np.int64)
+    rng = np.random.default_rng(99)
+    jobs = []
+    for i in range(40):
+        P = int(rng.integers(9, 60))
+        keys = [int(k) for k in rng.integers(0, 1 << c, size=P)]
+        if i % 2:
+            out, hits = eng.shared_scan(keys, col)
+            jobs.append(("shared", keys, out, hits))
+        else:
+            bm, hits = eng.scan_in(keys, col)
+            jobs.append(("in", keys, bm, hits))
+    torch.cuda.synchronize()
+    nb = (n + 7) // 8
+    for kind, keys, out, hits in jobs:
+        if kind == "shared":
+            expect = np.stack([np_bitmap(v == k) for k in keys])
+            assert np.array_equal(out.cpu().numpy()[:, :nb], expect)
+            assert np.array_equal(hits.cpu().numpy(), np.array([int((v == k).sum()) for k in keys]))
+        else:
+            member = np.isin(v, np.array(keys, dtype=np.int64))
+            assert np.array_equal(out.cpu().numpy(), np_bitmap(member)) and int(hits.item()) == int(member.sum())
+
+
 def test_scan_can_be_captured_in_a_hip_graph(O, eng):
     """the *_dev scan entry points only enqueue work (no allocation, no sync): capture one into a HIP graph on a
     side stream and replay it"""
