@@ -38,7 +38,9 @@ KAT = np.array([1, 2, 3, 3, 2, 1, 1, 2, 3, 1, 2, 3], dtype=np.uint32)
 
 def main():
     O = oracle()
-    here = os.path.dirname(os.path.abspath(__file__))
+    # output directory: this one, or argv[1] (tests/test_oracle_golden.py regenerates into a scratch directory and
+    # compares with the committed files)
+    here = sys.argv[1] if len(sys.argv) > 1 else os.path.dirname(os.path.abspath(__file__))
     for W in WIDTHS:
         R = RefLib(W)
         rng = np.random.default_rng(1000 + W)

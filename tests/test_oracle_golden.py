@@ -4,6 +4,8 @@ Golden vectors (tests/golden/ref_w*.npz) were produced by the reference's own fu
 from /root/reference (tests/golden/make_golden.py); the known-answer cases restate
 test/simd_scan_tests.cpp and test/util_tests.cpp of the reference.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -224,3 +226,27 @@ def test_cfg1_reference_vs_oracle_1e7(O):
     ref = R.shared_scan("shared_scan_128_standard", keys, packed8, n)
     mine, hits = O.shared_scan_eq(packed8, n, c, keys)
     assert np.array_equal(ref[:, : n // 8], mine) and hits.tolist() == [n // 8] * 8
+
+
+def test_committed_fixtures_are_what_the_reference_produces(tmp_path):
+    """tests/golden/*.npz are data produced by the reference itself: regenerating them with the committed script
+    (tests/golden/make_golden.py, which drives oracle/_ref = the reference compiled from its own sources) gives
+    array-for-array the committed files.  Needs oracle/_ref (built by __graft_entry__.build() where /root/reference
+    exists); skipped elsewhere."""
+    import glob
+    import subprocess
+    import sys
+
+    from oracle import ref_available
+
+    if not all(ref_available(w) for w in (5, 7, 9, 12, 17, 21)):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    subprocess.run([sys.executable, os.path.join(here, "make_golden.py"), str(tmp_path)], check=True, capture_output=True)
+    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(here, "*.npz")))
+    assert names == sorted(os.path.basename(f) for f in glob.glob(os.path.join(str(tmp_path), "*.npz")))
+    for name in names:
+        a, b = np.load(os.path.join(here, name)), np.load(os.path.join(str(tmp_path), name))
+        assert set(a.files) == set(b.files), name
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), (name, k)
