@@ -46,6 +46,7 @@ inline int scan_bpc(int occ_bpc, int tile_bytes, const LaunchReq &r)
     if (r.max_blocks_per_cu > 0) return r.max_blocks_per_cu < occ_bpc ? r.max_blocks_per_cu : occ_bpc;
     int want = (40 * 1024 + 2 * tile_bytes) / (kWavesPerBlock * tile_bytes); // rounded
     if (want < 1) want = 1;
+    if (want > 4) want = 4; // c = 1, 2 (1-2 KiB tiles): four blocks per CU beat eight by 20 % / 6 % (launches back to back)
     return want < occ_bpc ? want : occ_bpc;
 }
 
