@@ -117,18 +117,36 @@ def _cpu_model():
     return "unknown"
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed.run around it: this process becomes the
+    launcher.  It touches neither torch.cuda nor HIP; it starts N fresh rank processes (one per GPU) through
+    torch.distributed.run, lets rank 0's JSON line through on stdout and exits with the children's status."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback"
     # BENCH_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (ranks share devices);
     # the judged runs use nccl (= RCCL over xGMI), one rank per GPU
@@ -234,31 +252,45 @@ def main():
         got = [int(x) for x in hits.tolist()]
         assert got == want, f"shared-scan hits {got} != {want}"
 
-    gather_ms, gather_error, pipelined_ms = None, None, None
+    gather_ms, gather_error, pipelined_ms, gather_via = None, None, None, None
     if world > 1 and not args.no_gather and args.workload in ("scan_eq", "scan_range"):
-        # final exchange step of the north star: per-shard bitmaps -> rank 0 (RCCL over xGMI)
-        from shared_simd_scan_amd.sharded import gather_bitmaps
+        # final exchange step of the north star: per-shard bitmaps -> rank 0 over xGMI, through the C ABI's RCCL entry
+        # points (mi355_comm_create / mi355_gather_bitmaps_dev / mi355_allreduce_hits_dev); a gloo group (rehearsal on a
+        # box with fewer GPUs than ranks) uses the torch.distributed transport instead
+        from shared_simd_scan_amd.sharded import ShardedColumn, TorchExchange, make_exchange
 
-        sizes = None
         if args.scaling == "strong":
             sizes = [(b - a + 7) // 8 for a, b in shard_rows(args.rows, world)]
+        else:
+            sizes = [nb] * world
+        ex = None
         try:
-            full = gather_bitmaps(bitmap[:nb], dst=0, sizes=sizes)  # warm
+            ex = make_exchange(eng, None)
+        except Exception as e:  # RCCL bootstrap through the C ABI failed: say so, fall back to torch's own group
+            gather_error = f"C-ABI RCCL exchange unavailable ({type(e).__name__}: {e}); torch.distributed used"
+            ex = TorchExchange(None)
+        gather_via = ex.name
+        try:
+            full = ex.gather(bitmap[:nb], sizes, dst=0, engine=eng)  # warm
+            total_hits = ex.sum_hits(hits, engine=eng)
             sync_all()
             g0 = time.perf_counter()
             reps = 5
             for _ in range(reps):
-                full = gather_bitmaps(bitmap[:nb], dst=0, out=full, sizes=sizes)
+                full = ex.gather(bitmap[:nb], sizes, dst=0, out=full, engine=eng)
             sync_all()
             gather_ms = (time.perf_counter() - g0) / reps * 1e3
             gather_ms = reduce_max(gather_ms)
+            if expect_hits is not None and args.scaling == "weak":
+                want = sum(((r + 1) * n - 3 + 4) // 5 - (r * n - 3 + 4) // 5 for r in range(world))
+                assert int(total_hits.item()) == want, f"all-reduced hits {int(total_hits.item())} != {want}"
+            if rank == 0:  # the root's own slice must have arrived where the packed layout puts it
+                assert torch.equal(full[:nb], bitmap[:nb]), "gathered bitmap: the root's own slice differs"
         except Exception as e:  # the scan figures above stand on their own; report the exchange step as failed
             gather_error = f"{type(e).__name__}: {e}"
-        if args.pipelined_gather and args.workload == "scan_eq" and gather_error is None:
+        if args.pipelined_gather and args.workload == "scan_eq" and gather_ms is not None:
             try:
-                from shared_simd_scan_amd.sharded import ShardedColumn
-
-                sc = ShardedColumn(total_rows, c, engine=eng)
+                sc = ShardedColumn(total_rows, c, engine=eng, exchange=ex)
                 if args.scaling == "weak":  # every rank owns exactly --rows rows
                     sc.ranges = [(r * n, (r + 1) * n) for r in range(world)]
                     sc.first, sc.last, sc.rows = first, first + n, n
@@ -279,6 +311,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rows / (elapsed / args.steps)
         achieved = algo_bytes / (dev_ms * 1e-3) / 1e9
+        read_gbs = n * c / 8 / (dev_ms * 1e-3) / 1e9
+        traffic, traffic_src = _pmc_traffic(args, kname)
         line = {
             # BASELINE.json: "scanned values/sec + achieved HBM GB/s, 1e9 x 9-bit column, 1/2/4/8 GPU";
             # `value` is the values/sec half, `achieved_hbm_gb_per_s` (= roofline.achieved) the other
@@ -291,12 +325,15 @@ def main():
                                    + (f"keys=0..7, layout={args.layout}" if args.workload == "shared_scan" else f"key={key}"),
                        "rows_per_gpu": n, "bits": c, "parallelism": f"row-range shards x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(args, kname),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "kernel_ms": dev_ms, "algorithmic_bytes": algo_bytes,
-                         "read_gb_per_s": n * c / 8 / (dev_ms * 1e-3) / 1e9},
+                         # BASELINE.md section 3 words the target on the READ stream (>= 5.6 TB/s = 0.70 of peak)
+                         "read_gb_per_s": read_gbs, "read_frac": read_gbs / HBM_PEAK_GBS},
             "achieved_hbm_gb_per_s": achieved * world,  # all ranks (weak scaling: every GPU streams its own shard)
             "hits": int(hits.sum().item()) if hits is not None else None,
         }
+        if gather_via is not None:
+            line["gather_via"] = gather_via
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
             line["gather_gb_per_s"] = (total_rows / 8 - nb) / (gather_ms * 1e-3) / 1e9
@@ -313,17 +350,23 @@ def main():
 
 
 def _pmc_traffic(args, kname):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc.json), collected and
-    corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950, separate passes).  null when no
-    matching profile is committed for this workload/size."""
+    """(HBM bytes per launch, provenance) from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: collected
+    in separate --pmc passes and corrected as MI355X_MICROARCH.md prescribes, FETCH_SIZE x2 on gfx950).  The figure is
+    only reported while the device-side sources still hash to what the profile was taken on: otherwise (None, why)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         table = json.load(open(path))
     except (OSError, ValueError):
-        return None
-    key = f"{args.workload}:{args.rows}:{args.bits}"
-    ent = table.get(key)
-    return ent.get("hbm_bytes_per_launch") if ent else None
+        return None, "no profiles/pmc_traffic.json"
+    ent = table.get(f"{args.workload}:{args.rows}:{args.bits}")
+    if not ent:
+        return None, "no committed PMC profile for this workload / size"
+    from shared_simd_scan_amd.build import kernel_sources_sha
+
+    sha = kernel_sources_sha()
+    if ent.get("kernel_sources_sha") != sha:
+        return None, f"stale: profiles/{ent.get('source')} was taken on kernel sources {ent.get('kernel_sources_sha')}, now {sha}"
+    return ent.get("hbm_bytes_per_launch"), f"profiles/{ent.get('source')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, kernel sources {sha})"
 
 
 if __name__ == "__main__":

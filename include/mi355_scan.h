@@ -25,8 +25,13 @@
  *     (reference behaviour, SURVEY 8c hazard 5).
  *   - *_dev functions take DEVICE pointers, enqueue on the context's stream and return without
  *     synchronising; the others take HOST pointers, copy in/out and return when done.
- *   - a context binds one device and one stream and owns scratch the kernels use: calls on ONE context must not
- *     run concurrently from several threads (use one context per thread / stream); different contexts are independent.
+ *   - a context binds one device and one stream and owns the scratch the kernels use.  Threading contract (the
+ *     reference's functions are stateless and re-entrant; its own shared_scan_128_threaded calls scan_128 from an
+ *     OpenMP loop, src/simd_scan_shared.cpp:25-32): every entry point may be called from any number of host threads.
+ *     ctx == NULL is the CALLING THREAD's default context (own scratch, own buffer pool; device 0, the null stream),
+ *     so concurrent drop-in calls never share state.  An explicit context may be shared by threads too: each call
+ *     holds the context's lock while it touches it (host-pointer calls for their whole duration), i.e. calls on one
+ *     context serialise; use one context per thread / stream for concurrency.
  *   - there is no CPU fallback: without a usable gfx950 device every compute entry point fails
  *     with MI355_E_NODEVICE / MI355_E_HIP.
  */
@@ -50,6 +55,7 @@ extern "C" {
 #define MI355_E_INVALID (-1)  /* bad argument (width, null pointer, alignment, P) */
 #define MI355_E_HIP (-2)      /* a HIP runtime call failed */
 #define MI355_E_NODEVICE (-3) /* no gfx950 device visible */
+#define MI355_E_COMM (-4)     /* RCCL unavailable or an RCCL call failed (multi-GPU exchange step only) */
 
 #define MI355_LAYOUT_PER_PREDICATE 0 /* src/simd_scan_shared.cpp:82  outputs[key][group]      */
 #define MI355_LAYOUT_LINEAR 1        /* src/simd_scan_shared_linear.cpp:57  outputs[group*P+key] */
@@ -64,8 +70,9 @@ typedef struct mi355_ctx mi355_ctx;
 MI355_API const char *mi355_last_error(void);
 MI355_API const char *mi355_version(void);
 
-/* ---- context: device + stream.  ctx == NULL in any call below means the process-wide default
- * context (device 0, its null stream), created on first use. -------------------------------- */
+/* ---- context: device + stream.  ctx == NULL in any call below means the calling thread's default
+ * context (device 0, the null stream), created on the thread's first use and destroyed when the thread
+ * exits; mi355_ctx_set_option(NULL, ...) therefore configures the calling thread only. ------------- */
 MI355_API int mi355_ctx_create(int device, void *hip_stream /* hipStream_t or NULL */, mi355_ctx **out);
 MI355_API int mi355_ctx_destroy(mi355_ctx *ctx);
 MI355_API int mi355_ctx_synchronize(mi355_ctx *ctx);
@@ -75,6 +82,9 @@ MI355_API int mi355_device_count(int *count);
  * exceptions: mi355_shared_scan_eq_dev / mi355_scan_in_dev with P > 8 upload the key list per call (asynchronously,
  * through a ring of pinned slots: no stream synchronisation, but refused while the stream is capturing), and
  * mi355_bitmap_to_rowids_dev may grow its workspace) */
+/* Scratch, key slots and the buffer pool belong to the context, not to a stream: when neither stream is being captured,
+ * work already enqueued on the old stream is ordered before anything enqueued on the new one (event wait, no host
+ * synchronisation).  While either stream is capturing the caller orders the two. */
 MI355_API int mi355_ctx_set_stream(mi355_ctx *ctx, void *hip_stream);
 /* tuning knobs: "max_blocks_per_cu" (0 = the engine's per-kernel default), "dma_aux" (bits 0-3: cache policy of
  * the HBM->LDS loads, 0 default / 2 non-temporal; bit 4: non-temporal output stores in decompress; default 18),
@@ -188,6 +198,45 @@ MI355_API int mi355_bitmap_to_rowids_dev(mi355_ctx *ctx, const void *bitmap_dev,
  * column split over `world` ranks at multiples of 8192 rows, so every shard's packed slice starts 16-byte aligned on
  * a whole value and its bitmap slice on a whole byte.  Pure arithmetic, no device needed. */
 MI355_API int mi355_shard_rows(uint64_t n, unsigned world, unsigned rank, uint64_t *first, uint64_t *count);
+
+/* ---- multi-GPU exchange step: one process per GPU, one communicator rank per process, RCCL over xGMI.
+ * The scan itself needs no communication (rows are independent: rank r scans its own row range); the only exchange is
+ * the final gather of the per-shard bitmaps to one rank plus the sum of the hit counts.  RCCL is bound at run time
+ * (dlopen of librccl.so.1): hosts that never shard do not need it.  All calls enqueue on the context's stream and
+ * return without synchronising.
+ *   bootstrap: rank 0 calls mi355_comm_get_unique_id and hands the MI355_COMM_ID_BYTES bytes to every rank over any
+ *   host channel (file, socket, MPI, a torch.distributed store); every rank then calls mi355_comm_create (collective:
+ *   it returns once all `world` ranks have joined).  The communicator is bound to the context's device. */
+#define MI355_COMM_ID_BYTES 128
+typedef struct mi355_comm mi355_comm;
+MI355_API int mi355_comm_get_unique_id(void *id_out /* MI355_COMM_ID_BYTES */);
+MI355_API int mi355_comm_create(mi355_ctx *ctx, int world, int rank, const void *id, mi355_comm **out);
+MI355_API int mi355_comm_destroy(mi355_comm *comm);
+MI355_API int mi355_comm_info(const mi355_comm *comm, int *world, int *rank);
+/* gather: rank r contributes bytes_per_rank[r] bytes at local_dev (all ranks pass the same array); on `root` they land
+ * in out_dev at offset sum(bytes_per_rank[0..r)) -- grouped ncclSend / ncclRecv straight into the final buffer, the
+ * root's own slice a device-to-device copy (skipped when local_dev already is that slice of out_dev).  out_dev is
+ * ignored on the other ranks. */
+MI355_API int mi355_gather_bitmaps_dev(mi355_ctx *ctx, mi355_comm *comm, const void *local_dev, const uint64_t *bytes_per_rank,
+                                       int root, void *out_dev);
+/* the same with explicit destinations: rank r's bytes land at out_dev + offset_per_rank[r] (NULL: packed as above).
+ * Used to gather a shard piece by piece while later pieces are still being scanned (each piece of every rank goes
+ * straight to its place in the final bitmap). */
+MI355_API int mi355_gather_bitmaps_at_dev(mi355_ctx *ctx, mi355_comm *comm, const void *local_dev, const uint64_t *bytes_per_rank,
+                                          const uint64_t *offset_per_rank, int root, void *out_dev);
+/* in-place sum over the ranks of `count` device uint64 counters (ncclAllReduce): every rank gets the column-wide counts */
+MI355_API int mi355_allreduce_hits_dev(mi355_ctx *ctx, mi355_comm *comm, uint64_t *hits_dev, unsigned count);
+/* sharded scans = local scan of this rank's rows_per_rank[rank] rows (packed_dev = the rank's slice, starting on a
+ * whole value) + gather of the bitmaps to `root` + all-reduce of the hit count.  Every shard but the last must hold a
+ * multiple of 8 rows (mi355_shard_rows gives multiples of 8192).  local_bitmap_dev: >= ceil(rows/8) bytes, 16-byte
+ * aligned; full_bitmap_dev (root only): >= sum of the shards' bitmap bytes; hits_dev (nullable): the COLUMN-wide count
+ * on every rank. */
+MI355_API int mi355_sharded_scan_eq_dev(mi355_ctx *ctx, mi355_comm *comm, const void *packed_dev, unsigned c, int32_t key,
+                                        void *local_bitmap_dev, const uint64_t *rows_per_rank, int root, void *full_bitmap_dev,
+                                        uint64_t *hits_dev);
+MI355_API int mi355_sharded_scan_range_dev(mi355_ctx *ctx, mi355_comm *comm, const void *packed_dev, unsigned c, uint32_t lo,
+                                           uint32_t hi, void *local_bitmap_dev, const uint64_t *rows_per_rank, int root,
+                                           void *full_bitmap_dev, uint64_t *hits_dev);
 
 /* ---- introspection used by bench.py / tests --------------------------------------------------- */
 /* name of the HIP kernel a given op dispatches to at width c ("scan_eq", "scan_range", "shared_scan",

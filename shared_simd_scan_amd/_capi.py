@@ -12,6 +12,7 @@ OK = 0
 LAYOUT_PER_PREDICATE = 0
 LAYOUT_LINEAR = 1
 GEN_MOD, GEN_SPLITMIX, GEN_INDEX = 0, 1, 2
+COMM_ID_BYTES = 128
 
 # every symbol include/mi355_scan.h declares: (name, restype, argtypes)
 _vp, _u64, _u32, _i32, _sz, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_size_t, C.c_int
@@ -52,6 +53,15 @@ SYMBOLS = [
     ("mi355_bitmap_combine_dev", _int, [_vp, _int, _vp, _vp, _vp, _u64, _vp]),
     ("mi355_bitmap_count_dev", _int, [_vp, _vp, _u64, _vp]),
     ("mi355_bitmap_to_rowids_dev", _int, [_vp, _vp, _u64, _u64, _vp, _u64, _vp]),
+    ("mi355_comm_get_unique_id", _int, [_vp]),
+    ("mi355_comm_create", _int, [_vp, _int, _int, _vp, C.POINTER(_vp)]),
+    ("mi355_comm_destroy", _int, [_vp]),
+    ("mi355_comm_info", _int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
+    ("mi355_gather_bitmaps_dev", _int, [_vp, _vp, _vp, _vp, _int, _vp]),
+    ("mi355_gather_bitmaps_at_dev", _int, [_vp, _vp, _vp, _vp, _vp, _int, _vp]),
+    ("mi355_allreduce_hits_dev", _int, [_vp, _vp, _vp, C.c_uint]),
+    ("mi355_sharded_scan_eq_dev", _int, [_vp, _vp, _vp, C.c_uint, _i32, _vp, _vp, _int, _vp, _vp]),
+    ("mi355_sharded_scan_range_dev", _int, [_vp, _vp, _vp, C.c_uint, _u32, _u32, _vp, _vp, _int, _vp, _vp]),
     ("mi355_kernel_name", C.c_char_p, [C.c_char_p, C.c_uint]),
     ("mi355_tile_values", _u64, [C.c_uint]),
 ]

@@ -20,5 +20,19 @@ def build(jobs: int = 8, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def kernel_sources_sha() -> str:
+    """sha256 (first 16 hex digits) over the device-side sources: identifies the kernels a profile was taken on"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "kernels", "*.hpp"))) + [os.path.join(CSRC, f) for f in
+                                                                           ("kernels.hpp", "dispatch.hpp", "width_group.hip")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 if __name__ == "__main__":
     print(build(verbose=True))

@@ -3,16 +3,10 @@
 // Host-side plumbing only: argument checks, device buffers, stream ordering, kernel dispatch by
 // width.  All arithmetic of the path happens in the HIP kernels of kernels.hpp; there is no CPU
 // implementation of any operation in this library.
-#include "../../include/mi355_scan.h"
+#include "ctx.hpp"
 
-#include <hip/hip_runtime.h>
-
-#include <cstdarg>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
-#include <string>
 #include <vector>
 
 #include "dispatch.hpp"
@@ -20,31 +14,29 @@
 
 using namespace mi355;
 
-struct mi355_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    int num_cus = 256;
-    int max_blocks_per_cu = 0;
-    int scan_nt_stores = -1; // -1: by bitmap size (see width_group.hip), 0 plain, 1 non-temporal
-    int dma_aux = 18; // bits 0-3: policy of the HBM->LDS loads (2 = non-temporal: the column is streamed once);
-                      // bit 4: non-temporal stores in decompress
-    unsigned long long *hits_scratch = nullptr; // host-pointer API: where the kernels deliver hit counts
-    unsigned long long *kernel_scratch = nullptr; // kScratchWords words, all zero between launches (kernels.hpp hits_finalize)
-    // key lists longer than 8 travel through device memory: a ring of kKeySlots pinned host slots and device slots of
-    // 1024 + 8 keys each, so uploading a list never waits for the stream (only for the copy that used the slot
-    // kKeySlots calls ago)
-    int32_t *keys_scratch = nullptr;            // device: kKeySlots x (1024 + 8) keys
-    int32_t *keys_pinned = nullptr;             // host (pinned): the same
-    hipEvent_t key_events[8] = {};
-    bool key_used[8] = {};
-    int key_next = 0;
-    unsigned long long *rowid_ws = nullptr;     // chunk counts of mi355_bitmap_to_rowids_dev
-    size_t rowid_ws_entries = 0;
-};
+namespace mi355 {
 
 namespace {
-
 thread_local std::string g_err;
+
+// The default context is per THREAD: the reference's functions are stateless and re-entrant (its own
+// shared_scan_128_threaded calls scan_128 from an OpenMP loop, src/simd_scan_shared.cpp:25-32), so the drop-in path
+// (ctx == NULL everywhere in include/simd_scan.hpp) must be callable from several host threads at once.  Each thread
+// gets its own context -- own hit-count scratch, kernel scratch, key ring, device-buffer pool -- on device 0 and the
+// null stream; it is destroyed when the thread exits.
+struct ThreadDefault {
+    mi355_ctx *ctx = nullptr;
+    ~ThreadDefault()
+    {
+        if (ctx) {
+            mi355_ctx *c = ctx;
+            ctx = nullptr;
+            (void)mi355_ctx_destroy(c);
+        }
+    }
+};
+thread_local ThreadDefault t_default;
+} // namespace
 
 int fail(int code, const char *fmt, ...)
 {
@@ -57,27 +49,49 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                                  \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) return fail(MI355_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));        \
-    } while (0)
-
-
-std::mutex g_default_mu;
-mi355_ctx *g_default = nullptr;
+const char *last_error() { return g_err.c_str(); }
 
 int resolve(mi355_ctx *&ctx)
 {
     if (ctx) return MI355_OK;
-    std::lock_guard<std::mutex> lk(g_default_mu);
-    if (!g_default) {
-        int rc = mi355_ctx_create(0, nullptr, &g_default);
+    if (!t_default.ctx) {
+        int rc = mi355_ctx_create(0, nullptr, &t_default.ctx);
         if (rc != MI355_OK) return rc;
+        t_default.ctx->is_thread_default = true;
     }
-    ctx = g_default;
+    ctx = t_default.ctx;
     return MI355_OK;
 }
+
+int bind(mi355_ctx *ctx)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) return fail(MI355_E_HIP, "hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e));
+    }
+    return MI355_OK;
+}
+
+int pool_get(mi355_ctx *ctx, int slot, size_t bytes, void **out)
+{
+    if (ctx->pool_bytes[slot] < bytes) {
+        // whatever still uses the old buffer is ordered on the context's stream
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->pool[slot]) HIP_TRY(hipFree(ctx->pool[slot]));
+        ctx->pool[slot] = nullptr;
+        ctx->pool_bytes[slot] = 0;
+        const size_t want = (bytes + (bytes >> 3) + 4095) / 4096 * 4096; // 12 % slack: sizes that creep up do not reallocate each call
+        HIP_TRY(hipMalloc(&ctx->pool[slot], want));
+        ctx->pool_bytes[slot] = want;
+    }
+    *out = ctx->pool[slot];
+    return MI355_OK;
+}
+
+} // namespace mi355
+
+namespace {
 
 int check_width(unsigned c)
 {
@@ -88,17 +102,6 @@ int check_width(unsigned c)
 typedef hipError_t (*group_fn)(const LaunchReq &);
 const group_fn kGroups[kNumGroups] = {launch_group_0, launch_group_1, launch_group_2, launch_group_3,
                                       launch_group_4, launch_group_5, launch_group_6, launch_group_7};
-
-// a context is bound to one device: make it current for this thread before touching it
-int bind(mi355_ctx *ctx)
-{
-    int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) {
-        hipError_t e = hipSetDevice(ctx->device);
-        if (e != hipSuccess) return fail(MI355_E_HIP, "hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e));
-    }
-    return MI355_OK;
-}
 
 int launch(mi355_ctx *ctx, LaunchReq &r)
 {
@@ -139,22 +142,14 @@ int upload_keys(mi355_ctx *ctx, const int32_t *keys_host, unsigned P, const int3
     return MI355_OK;
 }
 
-struct DevBuf { // RAII for the host-pointer (copying) entry points
-    void *p = nullptr;
-    ~DevBuf()
-    {
-        if (p) (void)hipFree(p);
-    }
-};
-
 size_t bitmap_bytes(uint64_t n) { return (size_t)((n + 7) / 8); }
 
 } // namespace
 
 extern "C" {
 
-const char *mi355_last_error(void) { return g_err.c_str(); }
-const char *mi355_version(void) { return "mi355scan 0.1 (gfx950)"; }
+const char *mi355_last_error(void) { return mi355::last_error(); }
+const char *mi355_version(void) { return "mi355scan 0.2 (gfx950)"; }
 
 int mi355_device_count(int *count)
 {
@@ -188,19 +183,22 @@ int mi355_ctx_create(int device, void *hip_stream, mi355_ctx **out)
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *s = getenv("MI355_MAX_BLOCKS_PER_CU")) c->max_blocks_per_cu = atoi(s);
     if (const char *s = getenv("MI355_DMA_AUX")) c->dma_aux = atoi(s);
-    hipError_t e = hipMalloc((void **)&c->hits_scratch, kMaxKeys * sizeof(unsigned long long));
+    // host-pointer flavours: the kernels write the hit counts here, straight into pinned (device-visible) host memory
+    hipError_t e = hipHostMalloc((void **)&c->hits_scratch, kMaxKeys * sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&c->kernel_scratch, kScratchWords * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->kernel_scratch, 0, kScratchWords * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&c->keys_scratch, 8 * (kMaxKeys + 8) * sizeof(int32_t));
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->keys_pinned, 8 * (kMaxKeys + 8) * sizeof(int32_t), hipHostMallocDefault);
     for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->key_events[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->order_event, hipEventDisableTiming);
     if (e != hipSuccess) {
-        (void)hipFree(c->hits_scratch); // hipFree(nullptr) is a no-op
+        if (c->hits_scratch) (void)hipHostFree(c->hits_scratch);
         (void)hipFree(c->kernel_scratch);
         (void)hipFree(c->keys_scratch);
         if (c->keys_pinned) (void)hipHostFree(c->keys_pinned);
         for (int i = 0; i < 8; i++)
             if (c->key_events[i]) (void)hipEventDestroy(c->key_events[i]);
+        if (c->order_event) (void)hipEventDestroy(c->order_event);
         delete c;
         return fail(MI355_E_HIP, "hipMalloc(scratch): %s", hipGetErrorString(e));
     }
@@ -213,17 +211,15 @@ int mi355_ctx_destroy(mi355_ctx *ctx)
     if (!ctx) return MI355_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ctx->hits_scratch);
+    if (ctx->hits_scratch) (void)hipHostFree(ctx->hits_scratch);
     (void)hipFree(ctx->kernel_scratch);
     (void)hipFree(ctx->keys_scratch);
     if (ctx->keys_pinned) (void)hipHostFree(ctx->keys_pinned);
     for (int i = 0; i < 8; i++)
         if (ctx->key_events[i]) (void)hipEventDestroy(ctx->key_events[i]);
+    if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     (void)hipFree(ctx->rowid_ws);
-    {
-        std::lock_guard<std::mutex> lk(g_default_mu);
-        if (g_default == ctx) g_default = nullptr;
-    }
+    for (int i = 0; i < mi355_ctx::kPoolSlots; i++) (void)hipFree(ctx->pool[i]);
     delete ctx;
     return MI355_OK;
 }
@@ -232,6 +228,7 @@ int mi355_ctx_synchronize(mi355_ctx *ctx)
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MI355_OK;
 }
@@ -240,7 +237,22 @@ int mi355_ctx_set_stream(mi355_ctx *ctx, void *hip_stream)
 {
     int rc = resolve(ctx);
     if (rc) return rc;
-    ctx->stream = (hipStream_t)hip_stream;
+    CtxLock lk(ctx->mu);
+    hipStream_t next = (hipStream_t)hip_stream;
+    if (next == ctx->stream) return MI355_OK;
+    if ((rc = bind(ctx))) return rc;
+    // The scratch, the key slots and the buffer pool belong to the context, not to a stream: work already enqueued on
+    // the old stream must be ordered before work on the new one.  A stream that is being captured cannot take part in
+    // that (and a captured graph is ordered by whoever launches it): then the caller orders the two streams.
+    hipStreamCaptureStatus c0 = hipStreamCaptureStatusNone, c1 = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(ctx->stream, &c0);
+    (void)hipStreamIsCapturing(next, &c1);
+    if (c0 == hipStreamCaptureStatusNone && c1 == hipStreamCaptureStatusNone && hipStreamQuery(ctx->stream) != hipSuccess) {
+        HIP_TRY(hipEventRecord(ctx->order_event, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(next, ctx->order_event, 0));
+    }
+    (void)hipGetLastError(); // hipStreamQuery's hipErrorNotReady is not a failure
+    ctx->stream = next;
     return MI355_OK;
 }
 
@@ -261,6 +273,7 @@ int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value)
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if (!name) return fail(MI355_E_INVALID, "name is null");
     if (!strcmp(name, "max_blocks_per_cu"))
         ctx->max_blocks_per_cu = value;
@@ -287,6 +300,7 @@ int mi355_dev_alloc(mi355_ctx *ctx, size_t bytes, void **dptr)
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if (!dptr) return fail(MI355_E_INVALID, "dptr is null");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
@@ -296,6 +310,7 @@ int mi355_dev_free(mi355_ctx *ctx, void *dptr)
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     HIP_TRY(hipFree(dptr));
     return MI355_OK;
 }
@@ -303,6 +318,7 @@ int mi355_dev_upload(mi355_ctx *ctx, void *dst_dev, const void *src_host, size_t
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MI355_OK;
@@ -311,6 +327,7 @@ int mi355_dev_download(mi355_ctx *ctx, void *dst_host, const void *src_dev, size
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MI355_OK;
@@ -319,6 +336,7 @@ int mi355_dev_memset(mi355_ctx *ctx, void *dst_dev, int value, size_t bytes)
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     HIP_TRY(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
     return MI355_OK;
 }
@@ -376,12 +394,14 @@ int mi355_pack_u16_dev(mi355_ctx *ctx, const uint16_t *values_dev, uint64_t n, u
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     return pack_launch(ctx, kSrcU16, values_dev, n, 0, 0, c, packed_dev);
 }
 int mi355_pack_u32_dev(mi355_ctx *ctx, const uint32_t *values_dev, uint64_t n, unsigned c, void *packed_dev)
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     return pack_launch(ctx, kSrcU32, values_dev, n, 0, 0, c, packed_dev);
 }
 int mi355_generate_dev(mi355_ctx *ctx, int kind, uint64_t first_row, uint64_t n, unsigned c, uint64_t param,
@@ -389,6 +409,7 @@ int mi355_generate_dev(mi355_ctx *ctx, int kind, uint64_t first_row, uint64_t n,
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     int src = kind == MI355_GEN_MOD ? kSrcMod : kind == MI355_GEN_SPLITMIX ? kSrcSplitmix : kind == MI355_GEN_INDEX ? kSrcIndex : -1;
     if (src < 0) return fail(MI355_E_INVALID, "unknown generator kind %d", kind);
     return pack_launch(ctx, src, nullptr, n, first_row, param, c, packed_dev);
@@ -398,16 +419,17 @@ static int pack_host(mi355_ctx *ctx, int src, const void *values, size_t elem, u
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if ((rc = check_width(c))) return rc;
     if (!packed_host || (!values && n)) return fail(MI355_E_INVALID, "null pointer");
-    HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf dv, dp;
+    if ((rc = bind(ctx))) return rc;
+    void *dv = nullptr, *dp = nullptr;
     size_t pbytes = mi355_compressed_buffer_size(c, n);
-    HIP_TRY(hipMalloc(&dv.p, n * elem + 16));
-    HIP_TRY(hipMalloc(&dp.p, pbytes + 16));
-    HIP_TRY(hipMemcpyAsync(dv.p, values, n * elem, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = pack_launch(ctx, src, dv.p, n, 0, 0, c, dp.p))) return rc;
-    HIP_TRY(hipMemcpyAsync(packed_host, dp.p, pbytes, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = pool_get(ctx, mi355_ctx::kPoolIn, n * elem + 16, &dv))) return rc;
+    if ((rc = pool_get(ctx, mi355_ctx::kPoolOut, pbytes + 16, &dp))) return rc;
+    HIP_TRY(hipMemcpyAsync(dv, values, n * elem, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pack_launch(ctx, src, dv, n, 0, 0, c, dp))) return rc;
+    HIP_TRY(hipMemcpyAsync(packed_host, dp, pbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MI355_OK;
 }
@@ -425,6 +447,7 @@ int mi355_decompress_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, uns
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if ((rc = check_width(c))) return rc;
     if (n == 0) return MI355_OK;
     if (!packed_dev || !out_dev) return fail(MI355_E_INVALID, "null device pointer");
@@ -470,6 +493,7 @@ int mi355_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsign
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     return scan_common_dev(ctx, kOpScanEq, packed_dev, n, c, (uint32_t)key, 0, bitmap_dev, hits_dev);
 }
 
@@ -478,6 +502,7 @@ int mi355_scan_range_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, uns
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if (lo > hi) {
         // empty range: all-zero bitmap, zero hits
         if ((rc = check_width(c))) return rc;
@@ -494,6 +519,7 @@ int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n,
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if ((rc = check_width(c))) return rc;
     if (P < 1 || P > (unsigned)kMaxKeys) return fail(MI355_E_INVALID, "P=%u outside 1..%u", P, kMaxKeys);
     if (!keys_host) return fail(MI355_E_INVALID, "keys is null");
@@ -539,6 +565,7 @@ int mi355_scan_where_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, uns
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if ((rc = check_width(c))) return rc;
     if (op < MI355_CMP_EQ || op > MI355_CMP_NOT_BETWEEN) return fail(MI355_E_INVALID, "unknown comparison %d", op);
     if (n == 0) {
@@ -595,6 +622,7 @@ int mi355_scan_in_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsign
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if ((rc = check_width(c))) return rc;
     if (P < 1 || P > (unsigned)kMaxKeys) return fail(MI355_E_INVALID, "P=%u outside 1..%u", P, kMaxKeys);
     if (!keys_host) return fail(MI355_E_INVALID, "keys is null");
@@ -660,6 +688,7 @@ int mi355_bitmap_combine_dev(mi355_ctx *ctx, int op, const void *a_dev, const vo
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if (op < MI355_BITMAP_AND || op > MI355_BITMAP_ANDNOT) return fail(MI355_E_INVALID, "unknown bitmap op %d", op);
     return bitmap_launch(ctx, op, a_dev, b_dev, out_dev, n, count_dev);
 }
@@ -668,6 +697,7 @@ int mi355_bitmap_count_dev(mi355_ctx *ctx, const void *bitmap_dev, uint64_t n, u
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if (!count_dev) return fail(MI355_E_INVALID, "count_dev is null");
     return bitmap_launch(ctx, kBitCount, bitmap_dev, nullptr, nullptr, n, count_dev);
 }
@@ -677,6 +707,7 @@ int mi355_bitmap_to_rowids_dev(mi355_ctx *ctx, const void *bitmap_dev, uint64_t 
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if ((rc = bind(ctx))) return rc;
     if (!count_dev) return fail(MI355_E_INVALID, "count_dev is null");
     if (n == 0) {
@@ -713,22 +744,34 @@ int mi355_bitmap_to_rowids_dev(mi355_ctx *ctx, const void *bitmap_dev, uint64_t 
     return MI355_OK;
 }
 
-/* ---- host-pointer (copying, synchronous) flavours: the drop-in path ---- */
+/* ---- host-pointer (copying, synchronous) flavours: the drop-in path ----
+ * Device buffers come from the context's grow-only pool (no hipMalloc / hipFree per call).  The reference's callers
+ * hand over compressed_buffer_size(c, n) bytes, pad included (src/simd_scan.hpp:20-26); only the payload travels, the
+ * pad the kernels may touch (<= 15 bytes past the payload) is zeroed on the device. */
+static int upload_packed(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, void **dp)
+{
+    const size_t payload = (size_t)((n * c + 7) / 8);
+    int rc = pool_get(ctx, mi355_ctx::kPoolIn, payload + 256, dp);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(*dp, packed_host, payload, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync((uint8_t *)*dp + payload, 0, 16, ctx->stream));
+    return MI355_OK;
+}
+
 int mi355_decompress(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, int32_t *out_host)
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if ((rc = check_width(c))) return rc;
     if (n == 0) return MI355_OK;
     if (!packed_host || !out_host) return fail(MI355_E_INVALID, "null pointer");
-    HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf dp, dout;
-    size_t pbytes = mi355_compressed_buffer_size(c, n);
-    HIP_TRY(hipMalloc(&dp.p, pbytes));
-    HIP_TRY(hipMalloc(&dout.p, n * 4));
-    HIP_TRY(hipMemcpyAsync(dp.p, packed_host, pbytes, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = mi355_decompress_dev(ctx, dp.p, n, c, (int32_t *)dout.p))) return rc;
-    HIP_TRY(hipMemcpyAsync(out_host, dout.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = bind(ctx))) return rc;
+    void *dp = nullptr, *dout = nullptr;
+    if ((rc = upload_packed(ctx, packed_host, n, c, &dp))) return rc;
+    if ((rc = pool_get(ctx, mi355_ctx::kPoolOut, n * 4, &dout))) return rc;
+    if ((rc = mi355_decompress_dev(ctx, dp, n, c, (int32_t *)dout))) return rc;
+    HIP_TRY(hipMemcpyAsync(out_host, dout, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MI355_OK;
 }
@@ -738,26 +781,24 @@ static int scan_host(mi355_ctx *ctx, int op, const void *packed_host, uint64_t n
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if ((rc = check_width(c))) return rc;
     if (hits) *hits = 0;
     if (n == 0) return MI355_OK;
     if (!packed_host || !bitmap_host) return fail(MI355_E_INVALID, "null pointer");
-    HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf dp, db;
-    size_t pbytes = mi355_compressed_buffer_size(c, n);
-    HIP_TRY(hipMalloc(&dp.p, pbytes));
-    HIP_TRY(hipMalloc(&db.p, bitmap_bytes(n) + 16));
-    HIP_TRY(hipMemcpyAsync(dp.p, packed_host, pbytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = bind(ctx))) return rc;
+    void *dp = nullptr, *db = nullptr;
+    if ((rc = upload_packed(ctx, packed_host, n, c, &dp))) return rc;
+    if ((rc = pool_get(ctx, mi355_ctx::kPoolOut, bitmap_bytes(n) + 16, &db))) return rc;
+    // the kernel delivers the hit count straight into pinned host memory: no second download
     if (op == kOpScanRange)
-        rc = mi355_scan_range_dev(ctx, dp.p, n, c, k0, k1, db.p, (uint64_t *)ctx->hits_scratch);
+        rc = mi355_scan_range_dev(ctx, dp, n, c, k0, k1, db, (uint64_t *)ctx->hits_scratch);
     else
-        rc = mi355_scan_eq_dev(ctx, dp.p, n, c, (int32_t)k0, db.p, (uint64_t *)ctx->hits_scratch);
+        rc = mi355_scan_eq_dev(ctx, dp, n, c, (int32_t)k0, db, (uint64_t *)ctx->hits_scratch);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(bitmap_host, db.p, bitmap_bytes(n), hipMemcpyDeviceToHost, ctx->stream));
-    uint64_t h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, ctx->hits_scratch, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(bitmap_host, db, bitmap_bytes(n), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (hits) *hits = h;
+    if (hits) *hits = (uint64_t)ctx->hits_scratch[0];
     return MI355_OK;
 }
 
@@ -777,6 +818,7 @@ static int shared_host(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsi
 {
     int rc = resolve(ctx);
     if (rc) return rc;
+    CtxLock lk(ctx->mu);
     if ((rc = check_width(c))) return rc;
     if (P < 1 || P > (unsigned)kMaxKeys) return fail(MI355_E_INVALID, "P=%u outside 1..%u", P, kMaxKeys);
     if (!keys) return fail(MI355_E_INVALID, "keys is null");
@@ -784,28 +826,25 @@ static int shared_host(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsi
     if (n == 0) return MI355_OK;
     if (!packed_host || (layout == MI355_LAYOUT_PER_PREDICATE ? !outputs : !linear_out))
         return fail(MI355_E_INVALID, "null pointer");
-    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = bind(ctx))) return rc;
     const size_t nb = bitmap_bytes(n);
     const size_t stride = (nb + 15) / 16 * 16;
-    DevBuf dp, dout;
-    size_t pbytes = mi355_compressed_buffer_size(c, n);
-    HIP_TRY(hipMalloc(&dp.p, pbytes));
-    HIP_TRY(hipMalloc(&dout.p, (layout == MI355_LAYOUT_PER_PREDICATE ? stride : nb) * P + 16));
-    HIP_TRY(hipMemcpyAsync(dp.p, packed_host, pbytes, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = mi355_shared_scan_eq_dev(ctx, dp.p, n, c, keys, P, layout, dout.p, stride, (uint64_t *)ctx->hits_scratch)))
+    void *dp = nullptr, *dout = nullptr;
+    if ((rc = upload_packed(ctx, packed_host, n, c, &dp))) return rc;
+    if ((rc = pool_get(ctx, mi355_ctx::kPoolOut, (layout == MI355_LAYOUT_PER_PREDICATE ? stride : nb) * P + 16, &dout))) return rc;
+    // the reference's shared scans return no counts: only count when the caller asked
+    if ((rc = mi355_shared_scan_eq_dev(ctx, dp, n, c, keys, P, layout, dout, stride, hits ? (uint64_t *)ctx->hits_scratch : nullptr)))
         return rc;
     if (layout == MI355_LAYOUT_PER_PREDICATE) {
         for (unsigned k = 0; k < P; k++) {
             if (!outputs[k]) return fail(MI355_E_INVALID, "outputs[%u] is null", k);
-            HIP_TRY(hipMemcpyAsync(outputs[k], (uint8_t *)dout.p + k * stride, nb, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(outputs[k], (uint8_t *)dout + k * stride, nb, hipMemcpyDeviceToHost, ctx->stream));
         }
     } else {
-        HIP_TRY(hipMemcpyAsync(linear_out, dout.p, nb * P, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(linear_out, dout, nb * P, hipMemcpyDeviceToHost, ctx->stream));
     }
-    std::vector<uint64_t> h(P);
-    HIP_TRY(hipMemcpyAsync(h.data(), ctx->hits_scratch, P * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (hits) memcpy(hits, h.data(), P * sizeof(uint64_t));
+    if (hits) memcpy(hits, ctx->hits_scratch, P * sizeof(uint64_t));
     return MI355_OK;
 }
 

@@ -4,14 +4,21 @@ The column shards trivially: rows are independent, so rank r owns the contiguous
 [r*rows_per_rank, (r+1)*rows_per_rank) and scans them with no communication.  Shard boundaries are multiples
 of the scan tile (8192 rows), so every shard's packed slice starts 16-byte aligned on a whole value and its
 bitmap slice on a whole byte.  The only exchange step is the final gather of the per-shard bitmaps to one rank
-(RCCL over xGMI when the process group is "nccl"; the same code runs on "gloo" for CPU tests) and the sum of
-the hit counts.
+and the sum of the hit counts.
+
+That exchange lives behind the C ABI (include/mi355_scan.h: mi355_comm_create, mi355_gather_bitmaps_dev,
+mi355_allreduce_hits_dev -- direct RCCL calls over xGMI, grouped ncclSend / ncclRecv straight into the root's final
+bitmap); `RcclExchange` below only calls those entry points.  torch.distributed is the host channel that hands the
+RCCL unique id to every rank, and -- `TorchExchange` -- the transport of the CPU rehearsal of this module (gloo,
+world_size 2, tests/test_sharded_gloo.py), where no GPU and no RCCL exist.
 
 The reference has no multi-device code; this follows SURVEY 8e.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -38,67 +45,188 @@ def bitmap_bytes(rows: int) -> int:
     return (rows + 7) // 8
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# the exchange step
+# ---------------------------------------------------------------------------------------------------------------
+
+class TorchExchange:
+    """Exchange over a torch.distributed process group: gloo on CPU tensors (tests, rehearsals on a box with fewer
+    GPUs than ranks -- device tensors are staged through host memory), or torch's own NCCL group.
+
+    Point-to-point: every remote slice is received at its final offset of the root's buffer -- no padding of ragged
+    shards to the largest one, no concatenation pass on the root."""
+
+    name = "torch.distributed"
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.staged = dist.get_backend(group) == "gloo"
+
+    def _global(self, r: int) -> int:
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def gather_at(self, local: torch.Tensor, sizes: Sequence[int], offsets: Sequence[int], dst: int, out: Optional[torch.Tensor],
+                  engine=None) -> None:
+        """rank r's sizes[r] bytes land at out[offsets[r]:] on `dst` (out: a tensor on the root, ignored elsewhere)"""
+        if self.staged and local.is_cuda:
+            local = local.cpu()
+        mine = sizes[self.rank]
+        if self.rank != dst:
+            if mine:
+                dist.send(local[:mine].contiguous(), dst=self._global(dst), group=self.group)
+            return
+        host = out
+        if self.staged and out.is_cuda:  # rehearsal on a box with fewer GPUs than ranks: receive on the host, copy up
+            host = torch.empty(out.numel(), dtype=torch.uint8)
+        reqs = []
+        for r in range(self.world):
+            if r == dst:
+                if mine:
+                    host[offsets[r]: offsets[r] + mine] = local[:mine]
+            elif sizes[r]:
+                reqs.append(dist.irecv(host[offsets[r]: offsets[r] + sizes[r]], src=self._global(r), group=self.group))
+        for q in reqs:
+            q.wait()
+        if host is not out:
+            for r in range(self.world):
+                if sizes[r]:
+                    out[offsets[r]: offsets[r] + sizes[r]] = host[offsets[r]: offsets[r] + sizes[r]].to(out.device)
+
+    def gather(self, local: torch.Tensor, sizes: Sequence[int], dst: int = 0, out: Optional[torch.Tensor] = None,
+               engine=None) -> Optional[torch.Tensor]:
+        total = sum(sizes)
+        if self.rank == dst and (out is None or out.numel() < total):
+            out = torch.empty(total, dtype=torch.uint8, device=local.device)
+        offsets = [sum(sizes[:r]) for r in range(self.world)]
+        self.gather_at(local, sizes, offsets, dst, out, engine=engine)
+        return out[:total] if self.rank == dst else None
+
+    def sum_hits(self, hits: torch.Tensor, engine=None) -> torch.Tensor:
+        dev = hits.device
+        total = hits.cpu().clone() if (self.staged and hits.is_cuda) else hits.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+        return total.to(dev)
+
+
+class RcclExchange:
+    """The product path: the exchange entry points of the C ABI (direct RCCL over xGMI).  One communicator rank per
+    process; the unique id travels over the torch.distributed group that launched the ranks."""
+
+    name = "mi355 C ABI (RCCL)"
+
+    def __init__(self, engine, group=None):
+        from . import _capi
+        from ._capi import check, lib
+
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        ident = [None]
+        if self.rank == 0:
+            buf = (C.c_uint8 * _capi.COMM_ID_BYTES)()
+            check(lib().mi355_comm_get_unique_id(buf))
+            ident[0] = bytes(buf)
+        src = 0 if group is None else dist.get_global_rank(group, 0)
+        dist.broadcast_object_list(ident, src=src, group=group)
+        self._comm = C.c_void_p()
+        idbuf = (C.c_uint8 * _capi.COMM_ID_BYTES).from_buffer_copy(ident[0])
+        check(lib().mi355_comm_create(engine._ctx, self.world, self.rank, idbuf, C.byref(self._comm)))
+
+    def close(self) -> None:
+        from ._capi import lib
+
+        if getattr(self, "_comm", None):
+            lib().mi355_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def gather_at(self, local: torch.Tensor, sizes: Sequence[int], offsets: Sequence[int], dst: int, out: Optional[torch.Tensor],
+                  engine=None) -> None:
+        from ._capi import check, lib
+
+        arr = (C.c_uint64 * self.world)(*[int(x) for x in sizes])
+        offs = (C.c_uint64 * self.world)(*[int(x) for x in offsets])
+        check(lib().mi355_gather_bitmaps_at_dev(engine._ctx, self._comm, local.data_ptr() if local.numel() else None, arr, offs,
+                                                dst, out.data_ptr() if self.rank == dst else None))
+
+    def gather(self, local: torch.Tensor, sizes: Sequence[int], dst: int = 0, out: Optional[torch.Tensor] = None,
+               engine=None) -> Optional[torch.Tensor]:
+        from ._capi import check, lib
+
+        total = sum(sizes)
+        if self.rank == dst and (out is None or out.numel() < total):
+            out = torch.empty(total, dtype=torch.uint8, device=local.device)
+        arr = (C.c_uint64 * self.world)(*[int(x) for x in sizes])
+        check(lib().mi355_gather_bitmaps_dev(engine._ctx, self._comm, local.data_ptr() if local.numel() else None, arr, dst,
+                                             out.data_ptr() if self.rank == dst else None))
+        return out[:total] if self.rank == dst else None
+
+    def sum_hits(self, hits: torch.Tensor, engine=None) -> torch.Tensor:
+        from ._capi import check, lib
+
+        total = hits.clone()
+        check(lib().mi355_allreduce_hits_dev(engine._ctx, self._comm, total.data_ptr(), total.numel()))
+        return total
+
+
+def make_exchange(engine=None, group=None):
+    """RCCL through the C ABI when the ranks own distinct GPUs (process group backend "nccl"); the torch.distributed
+    transport for gloo groups (CPU tests; several ranks sharing one GPU, which RCCL refuses).  MI355_EXCHANGE=torch|rccl
+    overrides."""
+    want = os.environ.get("MI355_EXCHANGE", "")
+    backend = dist.get_backend(group)
+    if want == "rccl" or (want != "torch" and backend == "nccl" and engine is not None and hasattr(engine, "_ctx")):
+        return RcclExchange(engine, group)
+    return TorchExchange(group)
+
+
 def gather_bitmaps(local: torch.Tensor, dst: int = 0, out: Optional[torch.Tensor] = None,
-                   sizes: Optional[List[int]] = None, group=None) -> Optional[torch.Tensor]:
-    """Gather per-shard bitmaps (uint8, shard r = bytes of rows of rank r) to rank `dst`.
-
-    Equal-sized shards use one dist.gather (RCCL: grouped send/recv into the root, all inbound xGMI links in
-    parallel); ragged shards (`sizes` = bytes per rank) are padded to the largest and trimmed on the root.
-    Returns the concatenated bitmap on `dst`, None elsewhere."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    if local.is_cuda and dist.get_backend(group) == "gloo":
-        # rehearsal of the N>1 path on a box with fewer GPUs than ranks: stage through host memory
-        res = gather_bitmaps(local.cpu(), dst=dst, out=None, sizes=sizes, group=group)
-        return res.to(local.device) if res is not None else None
-    nbytes = local.numel()
+                   sizes: Optional[List[int]] = None, group=None, exchange=None, engine=None) -> Optional[torch.Tensor]:
+    """Gather per-shard bitmaps (uint8, shard r = bytes of rows of rank r) to rank `dst`: the concatenated bitmap on
+    `dst`, None elsewhere.  `sizes` = bytes per rank (default: every rank sends local.numel() bytes)."""
+    ex = exchange if exchange is not None else TorchExchange(group)
     if sizes is None:
-        sizes = [nbytes] * world
-    biggest = max(sizes)
-    if nbytes != biggest:
-        padded = torch.zeros(biggest, dtype=torch.uint8, device=local.device)
-        padded[:nbytes] = local
-        local = padded
-    if rank == dst:
-        if out is None or out.numel() != biggest * world:
-            out = torch.empty(biggest * world, dtype=torch.uint8, device=local.device)
-        chunks = list(out.view(world, biggest).unbind(0))
-        dist.gather(local, gather_list=chunks, dst=dst, group=group)
-        if all(s == biggest for s in sizes):
-            return out
-        return torch.cat([chunks[r][: sizes[r]] for r in range(world)])
-    dist.gather(local, gather_list=None, dst=dst, group=group)
-    return None
+        sizes = [local.numel()] * ex.world
+    return ex.gather(local, sizes, dst=dst, out=out, engine=engine)
 
 
-def sum_hits(local_hits: torch.Tensor, group=None) -> torch.Tensor:
+def sum_hits(local_hits: torch.Tensor, group=None, exchange=None, engine=None) -> torch.Tensor:
     """All ranks get the column-wide hit count(s)."""
-    if local_hits.is_cuda and dist.get_backend(group) == "gloo":
-        return sum_hits(local_hits.cpu(), group).to(local_hits.device)
-    total = local_hits.clone()
-    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
-    return total
+    ex = exchange if exchange is not None else TorchExchange(group)
+    return ex.sum_hits(local_hits, engine=engine)
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# a column partitioned by row range
+# ---------------------------------------------------------------------------------------------------------------
 
 class ShardedColumn:
     """A packed column partitioned by row range over the ranks of a process group.
 
-    `local_scan(key, first_row, rows) -> (bitmap uint8[ceil(rows/8)], hits int64[1])` is the per-shard scan;
-    by default it is the HIP engine (no CPU fallback)."""
+    `engine` is the per-shard scan: the HIP engine (ScanEngine; no CPU fallback).  `base_row` is the global row index
+    of the column's row 0 (a column that is itself a slice of a larger one: generators hash the global index)."""
 
-    def __init__(self, n: int, c: int, engine=None, group=None):
-        self.n, self.c, self.group = n, c, group
+    def __init__(self, n: int, c: int, engine=None, group=None, base_row: int = 0, exchange=None):
+        self.n, self.c, self.group, self.base_row = n, c, group, base_row
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.ranges = shard_rows(n, self.world)
         self.first, self.last = self.ranges[self.rank]
         self.rows = self.last - self.first
         self.engine = engine
+        self.exchange = exchange if exchange is not None else make_exchange(engine, group)
         self.col = None
 
     def generate(self, kind: str, param: int = 0) -> None:
         """every rank synthesises its own slice from the global row index (no upload, no scatter)"""
-        self.col = self.engine.generate(kind, self.rows, self.c, param, first_row=self.first)
+        self.col = self.engine.generate(kind, self.rows, self.c, param, first_row=self.base_row + self.first)
 
     def scan(self, key: int, dst: int = 0):
         bitmap, hits = self.engine.scan(key, self.col)
@@ -110,70 +238,62 @@ class ShardedColumn:
 
     def scan_pipelined(self, key: int, dst: int = 0, chunks: int = 4):
         """Same result as scan().  The shard is scanned in `chunks` row ranges (boundaries at multiples of SHARD_ALIGN)
-        and the gather of range i is started asynchronously as soon as its scan is enqueued: with RCCL the transfer of
-        range i over xGMI runs while range i+1 is scanned (the gather, not the scan, dominates a multi-GPU
-        query).  Every rank sends `chunks` equal-sized pieces (short or empty ones are zero-padded); on the root, full
-        pieces land directly in the final bitmap."""
-        world, rank, eng = self.world, self.rank, self.engine
+        and the gather of range i is enqueued as soon as its scan is: with the RCCL exchange on a side stream the
+        transfer of range i over xGMI runs while range i+1 is scanned (the gather, not the scan, dominates a
+        multi-GPU query).  Every piece is received at its final offset of the root's bitmap."""
+        world, rank, eng, ex = self.world, self.rank, self.engine, self.exchange
         per_rank = max(b - a for a, b in self.ranges)
         per = -(-max(per_rank, 1) // max(1, chunks))
         per = -(-per // SHARD_ALIGN) * SHARD_ALIGN         # rows per piece, the same on every rank
         npieces = max(1, -(-per_rank // per))
-        cb = per // 8                                       # bytes per piece
+        cb = per // 8                                       # bytes per full piece
         sizes = [bitmap_bytes(b - a) for a, b in self.ranges]
         offs = [sum(sizes[:r]) for r in range(world)]
-        staged_via_host = None
-        final, temps, works, keep = None, [], [], []
+        dev = self._device()
+        final = torch.empty(sum(sizes), dtype=torch.uint8, device=dev) if rank == dst else None
+        # the exchange runs on a side stream (its own context on the same device), ordered behind each piece's scan
+        comm_eng, main, side = eng, None, None
+        if isinstance(ex, RcclExchange):
+            comm_eng, main, side = self._side_engine()
         hits_total = None
+        keep = []
         for i in range(npieces):
             a, b = min(self.rows, i * per), min(self.rows, (i + 1) * per)
-            piece = None
+            piece = torch.empty(0, dtype=torch.uint8, device=dev)
             if b > a:
                 bm, h = eng.scan(key, eng.slice_rows(self.col, a, b))
                 hits_total = h.clone() if hits_total is None else hits_total + h
                 piece = bm[: bitmap_bytes(b - a)]
-            if piece is None or piece.numel() != cb:
-                padded = torch.zeros(cb, dtype=torch.uint8, device=piece.device if piece is not None else self._device())
-                if piece is not None:
-                    padded[: piece.numel()] = piece
-                piece = padded
-            if staged_via_host is None:
-                staged_via_host = piece.is_cuda and dist.get_backend(self.group) == "gloo"
-            if staged_via_host:
-                piece = piece.cpu()  # rehearsal on a box with fewer GPUs than ranks: no overlap, same data path
-            gather_list = None
-            if rank == dst:
-                if final is None:
-                    final = torch.empty(sum(sizes), dtype=torch.uint8, device=piece.device)
-                gather_list = []
-                for r in range(world):
-                    rows_r = self.ranges[r][1] - self.ranges[r][0]
-                    valid = bitmap_bytes(max(0, min(per, rows_r - i * per)))
-                    if valid == cb:
-                        gather_list.append(final[offs[r] + i * cb: offs[r] + (i + 1) * cb])
-                    else:
-                        t = torch.empty(cb, dtype=torch.uint8, device=piece.device)
-                        temps.append((t, offs[r] + i * cb, valid))
-                        gather_list.append(t)
             keep.append(piece)
-            works.append(dist.gather(piece, gather_list=gather_list, dst=dst, group=self.group, async_op=True))
-        for w in works:
-            w.wait()
+            psizes = [bitmap_bytes(max(0, min(per, (self.ranges[r][1] - self.ranges[r][0]) - i * per))) for r in range(world)]
+            poffs = [offs[r] + i * cb for r in range(world)]
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+            ex.gather_at(piece, psizes, poffs, dst, final, engine=comm_eng)
+        if side is not None:
+            main.wait_stream(side)
         if hits_total is None:
-            hits_total = torch.zeros(1, dtype=torch.int64, device=self._device())
-        if rank == dst:
-            for t, off, valid in temps:
-                if valid:
-                    final[off: off + valid] = t[:valid]
-            if staged_via_host:
-                final = final.to(self._device())
-        return (final if rank == dst else None), sum_hits(hits_total, self.group)
+            hits_total = torch.zeros(1, dtype=torch.int64, device=dev)
+        return final, ex.sum_hits(hits_total, engine=eng)
+
+    def _side_engine(self):
+        """(engine bound to a side stream, main torch stream, side torch stream) for overlapping the exchange with scans"""
+        if getattr(self, "_side", None) is None:
+            from .engine import ScanEngine
+
+            side = torch.cuda.Stream(device=self.engine._dev)
+            self._side = (ScanEngine(self.engine.device, stream=side), self.engine.stream, side)
+        return self._side
 
     def _device(self):
         data = getattr(self.col, "data", None)
-        return data.device if isinstance(data, torch.Tensor) else torch.device("cpu")
+        if isinstance(data, torch.Tensor):
+            return data.device
+        return getattr(self.engine, "_dev", torch.device("cpu"))
 
     def _finish(self, bitmap, hits, dst):
         sizes = [bitmap_bytes(b - a) for a, b in self.ranges]
-        full = gather_bitmaps(bitmap[: sizes[self.rank]], dst=dst, sizes=sizes, group=self.group)
-        return full, sum_hits(hits, self.group)
+        full = self.exchange.gather(bitmap[: sizes[self.rank]], sizes, dst=dst, engine=self.engine)
+        return full, self.exchange.sum_hits(hits, engine=self.engine)

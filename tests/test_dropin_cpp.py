@@ -10,17 +10,27 @@ BIN = os.path.join(ROOT, "tests", "cpp", "build", "dropin_tests")
 LIBDIR = os.path.join(ROOT, "shared_simd_scan_amd")
 
 
-def build_binary():
+THREADS_SRC = os.path.join(ROOT, "tests", "cpp", "threads_tests.cpp")
+THREADS_BIN = os.path.join(ROOT, "tests", "cpp", "build", "threads_tests")
+
+
+def _compile(src, exe, extra=()):
     from shared_simd_scan_amd import build
 
     if not os.path.exists(build.LIB_PATH):
         build.build()
-    os.makedirs(os.path.dirname(BIN), exist_ok=True)
-    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(SRC), os.path.getmtime(
-            os.path.join(ROOT, "include", "simd_scan.hpp"))):
-        subprocess.run(["g++", "-std=gnu++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), SRC, "-o", BIN,
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "simd_scan.hpp")),
+                 os.path.getmtime(os.path.join(ROOT, "include", "mi355_scan.h")))
+    if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
+        subprocess.run(["g++", "-std=gnu++17", "-O1", "-Wall", *extra, "-I", os.path.join(ROOT, "include"), src, "-o", exe,
                         "-L", LIBDIR, "-lmi355scan", f"-Wl,-rpath,{LIBDIR}"], check=True)
-    return BIN
+    return exe
+
+
+def build_binary():
+    _compile(THREADS_SRC, THREADS_BIN, extra=("-pthread",))
+    return _compile(SRC, BIN)
 
 
 def test_dropin_header_compiles_and_links_with_plain_gxx():
@@ -35,6 +45,17 @@ def test_reference_unit_tests_pass_through_the_dropin_header():
     assert res.returncode == 0, res.stdout + res.stderr
     assert "All tests passed" in res.stdout
     assert "not supported for 3 predicate keys!" in res.stderr
+
+
+@pytest.mark.gpu
+def test_dropin_calls_from_eight_host_threads():
+    """the reference's functions are re-entrant (src/simd_scan_shared.cpp:25-32 calls scan_128 from an OpenMP loop):
+    8 threads x different keys through include/simd_scan.hpp, one explicit context shared by 8 threads, and threads
+    mixing 16-key shared scans / scans / decompression -- every bitmap and hit count checked (tests/cpp/threads_tests.cpp)"""
+    build_binary()
+    res = subprocess.run([THREADS_BIN], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "All thread tests passed" in res.stdout
 
 
 CLI = os.path.join(ROOT, "cli", "shared_simd_scan_mi355")

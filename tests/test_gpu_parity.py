@@ -490,6 +490,71 @@ def test_cfg4_shared_8_predicates_1e9_properties(O, eng):
     assert np.array_equal(out[:, a // 8: a // 8 + (ln + 7) // 8].cpu().numpy(), oout)
 
 
+def test_cfg4_random_column_1e9_both_layouts(O, eng):
+    """BASELINE config 4, second half: P=8 over the 1e9 x 9 bit RANDOM column, keys v[31k+5], both output
+    layouts.  Full-size, size-independent checks: bitmap k == the single-predicate scan of key k (a different kernel)
+    over all n/8 bytes, popcount == hits, linear == byte-transposition of the per-predicate bitmaps; oracle on windows
+    (start, middle, the ragged last tile)."""
+    import torch
+
+    n, c, P = 1_000_000_000, 9, 8
+    col = eng.generate("splitmix", n, c, 42)
+    keys = [int(O.gen_values("splitmix", 1, c, 42, first=31 * k + 5)[0]) for k in range(P)]
+    nb = n // 8
+    out, hits = eng.shared_scan(keys, col)
+    h = hits.cpu().tolist()
+    for k in range(P):
+        # duplicates among the keys are legal: every predicate is evaluated on its own
+        bm1, h1 = eng.scan(keys[k], col)
+        assert int(h1.item()) == h[k]
+        assert torch.equal(out[k, :nb], bm1[:nb])
+        assert int(eng.bitmap_count(out[k], n).item()) == h[k]
+        assert abs(h[k] - n / 512) < 6 * (n / 512) ** 0.5
+    del bm1
+    lin, hits2 = eng.shared_scan(keys, col, layout="linear")
+    assert hits2.cpu().tolist() == h
+    assert torch.equal(lin.view(nb, P).t(), out[:, :nb])
+    for a, ln in ((0, 150_000), (8192 * 60_007, 150_000), (n - 2560 - 8192 * 3, None)):
+        ln = n - a if ln is None else ln
+        pk = col.data[a * c // 8: a * c // 8 + (ln * c + 7) // 8].cpu().numpy()
+        assert np.array_equal(pk, O.pack(O.gen_values("splitmix", ln, c, 42, first=a), c)[: pk.shape[0]])
+        oout, ohits = O.shared_scan_eq(pk, ln, c, keys)
+        assert np.array_equal(out[:, a // 8: a // 8 + (ln + 7) // 8].cpu().numpy(), oout)
+        olin, _ = O.shared_scan_eq(pk, ln, c, keys, layout="linear")
+        assert np.array_equal(lin[a // 8 * P: (a // 8 + (ln + 7) // 8) * P].cpu().numpy(), olin)
+
+
+def test_cfg5_shard_1e9x12_at_first_row_7e9(O, eng):
+    """BASELINE config 5, the per-GPU workload of rank 7: rows [7e9, 8e9) of the 8e9 x 12 bit random column, equality
+    on key v[12345] of the GLOBAL column.  Full-size: popcount == hits, bitmap == decompress -> compare on
+    the device over all n/8 bytes; oracle windows at the start, in the middle and over the ragged last tile (1e9 is not
+    a multiple of the 8192-row tile), each with packed bytes == the oracle's generator at that global row."""
+    import torch
+
+    n, c, first = 1_000_000_000, 12, 7_000_000_000
+    col = eng.generate("splitmix", n, c, 42, first_row=first)
+    key = int(O.gen_values("splitmix", 1, c, 42, first=12345)[0])
+    bm, hits = eng.scan(key, col)
+    h = int(hits.item())
+    assert abs(h - n / 4096) < 6 * (n / 4096) ** 0.5
+    assert int(eng.bitmap_count(bm, n).item()) == h
+    dec = eng.decompress(col)
+    expect = dec == key
+    assert int(expect.sum().item()) == h
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device="cuda")
+    assert torch.equal(bm, (expect.view(-1, 8).to(torch.int32) * w).sum(dim=1).to(torch.uint8))
+    del expect
+    for a, ln in ((0, 200_000), (8192 * 50_021, 200_000), (n - 2560 - 8192 * 2, None)):
+        ln = n - a if ln is None else ln
+        pk = col.data[a * c // 8: a * c // 8 + (ln * c + 7) // 8].cpu().numpy()
+        assert np.array_equal(pk, O.pack(O.gen_values("splitmix", ln, c, 42, first=first + a), c)[: pk.shape[0]])
+        obm, _ = O.scan_eq(pk, ln, c, key)
+        assert np.array_equal(bm[a // 8: a // 8 + (ln + 7) // 8].cpu().numpy(), obm)
+        assert np.array_equal(dec[a: a + ln].cpu().numpy(), O.decompress(pk, ln, c))
+    del dec, bm, col
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------------
 # beyond the reference: comparisons, conjunctions, bitmap consumers (checked against numpy on the values)
 # ------------------------------------------------------------------------------------------------

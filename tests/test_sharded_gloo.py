@@ -130,3 +130,104 @@ def test_c_abi_shard_rows_matches_python():
                 assert (a.value, a.value + cnt.value) == py[r]
     a, cnt = C.c_uint64(), C.c_uint64()
     assert L.mi355_shard_rows(10, 2, 2, C.byref(a), C.byref(cnt)) == -1
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU (-m gpu): the same sharding logic with the real HIP engine
+# ------------------------------------------------------------------------------------------------
+
+def gpu_worker(rank, world, port, n, c, base_row, q):
+    """two ranks share cuda:0 (the box has one GPU); the exchange runs over gloo, staged through host memory"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle
+        from shared_simd_scan_amd import ScanEngine
+        from shared_simd_scan_amd.sharded import ShardedColumn, TorchExchange
+
+        O = oracle()
+        eng = ScanEngine(0)
+        sc = ShardedColumn(n, c, engine=eng, base_row=base_row)
+        assert isinstance(sc.exchange, TorchExchange)
+        sc.generate("splitmix", 42)
+        key = int(O.gen_values("splitmix", 1, c, 42, first=12345)[0])
+        full, hits = sc.scan(key, dst=0)
+        lo, hi = (1 << c) // 4, (1 << c) // 2
+        full_r, hits_r = sc.scan_range(lo, hi, dst=0)
+        full_p, hits_p = sc.scan_pipelined(key, dst=0, chunks=3)
+        if rank == 0:
+            vals = O.gen_values("splitmix", n, c, 42, first=base_row)
+            packed = O.pack(vals, c)
+            ref, ref_hits = O.scan_eq(packed, n, c, key)
+            ref_r, ref_hits_r = O.scan_range(packed, n, c, lo, hi)
+            ok = (full.is_cuda and np.array_equal(full.cpu().numpy(), ref) and int(hits.item()) == ref_hits
+                  and np.array_equal(full_p.cpu().numpy(), ref) and int(hits_p.item()) == ref_hits
+                  and np.array_equal(full_r.cpu().numpy(), ref_r) and int(hits_r.item()) == ref_hits_r)
+            q.put(("ok" if ok else "mismatch", sc.ranges))
+        else:
+            assert full is None and full_p is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c,base_row", [(8192 * 7 + 77, 9, 0), (2_000_003, 12, 7_000_000_000), (5, 12, 0)])
+def test_sharded_scan_world2_real_engine(n, c, base_row):
+    """ShardedColumn.scan / scan_range / scan_pipelined with ScanEngine under gloo, two ranks on one GPU; the second
+    case is BASELINE config 5's shard shape (c = 12, splitmix, rows starting at 7e9)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=gpu_worker, args=(r, world, port, n, c, base_row, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    status, ranges = q.get(timeout=10)
+    assert status == "ok", ranges
+
+
+@pytest.mark.gpu
+def test_c_abi_exchange_single_rank():
+    """The RCCL entry points of the C ABI with a communicator of one rank (the box has one GPU and RCCL refuses two ranks
+    on one device): bootstrap, gather to self at explicit offsets, all-reduce, sharded scan = local scan."""
+    import ctypes as C
+
+    from oracle import oracle
+    from shared_simd_scan_amd import ScanEngine, lib
+
+    O = oracle()
+    L = lib()
+    eng = ScanEngine(0)
+    ident = (C.c_uint8 * 128)()
+    assert L.mi355_comm_get_unique_id(ident) == 0, L.mi355_last_error()
+    comm = C.c_void_p()
+    assert L.mi355_comm_create(eng._ctx, 1, 0, ident, C.byref(comm)) == 0, L.mi355_last_error()
+    w, r = C.c_int(), C.c_int()
+    assert L.mi355_comm_info(comm, C.byref(w), C.byref(r)) == 0 and (w.value, r.value) == (1, 0)
+    n, c = 8192 * 5 + 123, 12
+    col = eng.generate("splitmix", n, c, 42)
+    key = int(O.gen_values("splitmix", 1, c, 42, first=777)[0])
+    nb = (n + 7) // 8
+    local = torch.zeros(nb + 16, dtype=torch.uint8, device="cuda")
+    full = torch.full((nb + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    hits = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rows = (C.c_uint64 * 1)(n)
+    assert L.mi355_sharded_scan_eq_dev(eng._ctx, comm, col.data.data_ptr(), c, key, local.data_ptr(), rows, 0,
+                                       full.data_ptr(), hits.data_ptr()) == 0, L.mi355_last_error()
+    ref, ref_hits = O.scan_eq(col.data.cpu().numpy(), n, c, key)
+    assert np.array_equal(full[:nb].cpu().numpy(), ref) and int(hits.item()) == ref_hits
+    assert bool((full[nb:] == 0xEE).all().item())  # nothing written past the gathered bytes
+    # explicit offsets
+    sizes, offs = (C.c_uint64 * 1)(nb), (C.c_uint64 * 1)(32)
+    full.fill_(0xEE)
+    assert L.mi355_gather_bitmaps_at_dev(eng._ctx, comm, local.data_ptr(), sizes, offs, 0, full.data_ptr()) == 0
+    assert np.array_equal(full[32: 32 + nb].cpu().numpy(), ref) and bool((full[:32] == 0xEE).all().item())
+    # argument checks
+    assert L.mi355_gather_bitmaps_dev(eng._ctx, comm, local.data_ptr(), sizes, 3, full.data_ptr()) == -1
+    assert L.mi355_allreduce_hits_dev(eng._ctx, comm, hits.data_ptr(), 1) == 0
+    assert int(hits.item()) == ref_hits
+    assert L.mi355_comm_destroy(comm) == 0

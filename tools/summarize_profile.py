@@ -13,6 +13,13 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _sha():
+    from shared_simd_scan_amd.build import kernel_sources_sha
+
+    return kernel_sources_sha()
 
 
 def main():
@@ -79,7 +86,8 @@ def main():
             table = {}
         table[f"{workload}:{rows}:{bits}"] = {"hbm_bytes_per_launch": out["hbm_bytes_per_launch"],
                                               "read": out["hbm_read_bytes_per_launch"],
-                                              "write": out["hbm_write_bytes_per_launch"], "source": os.path.basename(base) + ".json"}
+                                              "write": out["hbm_write_bytes_per_launch"], "source": os.path.basename(base) + ".json",
+                                              "kernel_sources_sha": _sha()}
         json.dump(table, open(tpath, "w"), indent=1)
     # the JSON line bench.py printed in pass 1 (its roofline.kernel_ms comes from HIP events in the SAME run as the
     # --stats average above) and the raw --stats kernel table
