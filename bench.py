@@ -45,14 +45,41 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --rows per GPU; strong: --rows in total, row-range sharded at 8192-row boundaries")
     ap.add_argument("--cpu-reps", type=int, default=5)
-    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the multi-core CPU leg (box share: 16)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the multi-core CPU leg (0 = every CPU this process may use: affinity mask / cgroup quota)")
     return ap.parse_args()
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU quota when one is set"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(args, col, gpu_bitmap, key):
-    """Reference CPU path on this host's cores, on the SAME column (downloaded from HBM).
-    kind 'reference': oracle/_ref (the reference's scan_256_unrolled, its fastest single-thread variant,
-    src/simd_scan.cpp:273) when the prebuilt .so travelled here; else kind 'port': oracle.c with OpenMP."""
+    """The reference's CPU path on this host's cores, on the SAME column (downloaded from HBM), never a scalar straw man:
+    kind 'reference'        : oracle/_ref, the reference's own scan_256_unrolled (its fastest single-thread variant,
+                              src/simd_scan.cpp:273), when the prebuilt .so travelled here;
+    kind 'avx2-restatement' : oracle/oracle_avx2.c, the own AVX2 restatement of that function (pinned to the reference's
+                              golden vectors, tests/test_oracle_golden.py) -- what a clean checkout has.
+    Both legs are reported when both exist.  `cores` = threads actually used: 1 for the headline figure (the reference is
+    single-threaded), and an all-cores leg (row-range slices over the CPUs this process may use) beside it."""
     import numpy as np
 
     from oracle import RefLib, oracle, ref_available
@@ -61,18 +88,36 @@ def cpu_baseline(args, col, gpu_bitmap, key):
     packed = col.data.cpu().numpy()
     nb = (n + 7) // 8
     gpu_host = gpu_bitmap[:nb].cpu().numpy()
+    O = oracle()
+    share = host_cpu_share()
+    threads = max(1, min(args.cpu_threads if args.cpu_threads > 0 else share, share))
+    host = {"host_cpu": _cpu_model(), "host_cores": os.cpu_count(), "host_cpu_share": share}
+    reps = max(1, args.cpu_reps)
+
+    restated = None
+    if O.avx2_available() and c <= 25:
+        out, hits, secs = O.scan_eq_avx2(packed, n, c, key, threads=1, reps=reps)
+        t = float(np.median(secs))
+        restated = {"value": n / t, "unit": "values/s", "cores": 1, "kind": "avx2-restatement",
+                    "sample": f"full column ({n} values), oracle_avx2.c (AVX2 in-place compare, 32 values per bitmap word), "
+                              f"median of {reps} reps, 1 thread",
+                    "ms": t * 1e3, "gb_per_s": n * c / 8 / t / 1e9, "bitmap_equals_gpu": bool(np.array_equal(out, gpu_host)),
+                    "hits": hits}
+        if threads > 1:
+            out, hits_mt, secs = O.scan_eq_avx2(packed, n, c, key, threads=threads, reps=max(3, reps))
+            best = float(min(secs))
+            restated["all_cores"] = {"value": n / best, "unit": "values/s", "cores": threads, "ms": best * 1e3,
+                                     "hits": hits_mt, "bitmap_equals_gpu": bool(np.array_equal(out, gpu_host)),
+                                     "sample": f"same column, OpenMP row ranges over {threads} threads, best of {max(3, reps)}"}
     if c == 9 and ref_available(9):
         R = RefLib(9)
-        secs, out, hits = R.scan_timed("scan_256_unrolled", key, packed, n, args.cpu_reps)
+        secs, out, hits = R.scan_timed("scan_256_unrolled", key, packed, n, reps)
         t = float(np.median(secs))
-        same = bool(np.array_equal(out[:nb], gpu_host))
         res = {"value": n / t, "unit": "values/s", "cores": 1, "kind": "reference",
-               "sample": f"full column ({n} values), scan_256_unrolled, median of {args.cpu_reps} reps, 1 thread",
-               "ms": t * 1e3, "gb_per_s": n * c / 8 / t / 1e9, "bitmap_equals_gpu": same,
-               "host_cpu": _cpu_model(), "host_cores": os.cpu_count()}
+               "sample": f"full column ({n} values), scan_256_unrolled, median of {reps} reps, 1 thread",
+               "ms": t * 1e3, "gb_per_s": n * c / 8 / t / 1e9, "bitmap_equals_gpu": bool(np.array_equal(out[:nb], gpu_host))}
         # the same reference function on row-range slices, one thread per slice (the reference itself is
         # single-threaded; this is what its AVX2 path gives when the host's cores share the column)
-        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
         if threads > 1:
             from concurrent.futures import ThreadPoolExecutor
 
@@ -93,18 +138,15 @@ def cpu_baseline(args, col, gpu_bitmap, key):
                     best = dt if best is None else min(best, dt)
             res["all_cores"] = {"value": n / best, "unit": "values/s", "cores": len(slices), "ms": best * 1e3,
                                 "hits": int(hits_mt), "sample": "same column, row-range slices, one reference call per thread"}
+        if restated is not None:
+            res["avx2_restatement"] = restated  # the clean-checkout leg, for comparison on the same host
+        res.update(host)
         return res
-    O = oracle()
-    ts = []
-    for _ in range(max(1, min(args.cpu_reps, 3))):
-        t0 = time.perf_counter()
-        out, hits = O.scan_eq(packed, n, c, key)
-        ts.append(time.perf_counter() - t0)
-    t = float(np.median(ts))
-    return {"value": n / t, "unit": "values/s", "cores": O.num_threads(), "kind": "port",
-            "sample": f"full column ({n} values), oracle.c scalar restatement, OpenMP row-range", "ms": t * 1e3,
-            "bitmap_equals_gpu": bool(np.array_equal(out, gpu_host)), "host_cpu": _cpu_model(),
-            "host_cores": os.cpu_count()}
+    if restated is not None:
+        restated.update(host)
+        return restated
+    raise RuntimeError("cpu_baseline: neither oracle/_ref nor an AVX2 host: refusing to time a scalar straw man "
+                       "(run with --no-cpu-baseline)")
 
 
 def _cpu_model():

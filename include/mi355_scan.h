@@ -173,6 +173,17 @@ MI355_API int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, u
  * >= ceil(n/8) bytes, 16-byte aligned -- chains conjunctions over several columns without a separate AND pass. */
 MI355_API int mi355_scan_where_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int op, int64_t a, int64_t b,
                                    const void *and_mask_dev, void *bitmap_dev, uint64_t *hits_dev);
+/* The general form, fused consumers included (the intent of src/simd_scan.hpp:76-84):
+ *   p[i]      = (v_i OP a [, b])
+ *   bitmap[i] = mask_dev ? COMBINE(p[i], mask[i]) : p[i]     mask_op: MI355_BITMAP_AND  p & mask   (conjunction)
+ *                                                                      MI355_BITMAP_OR   p | mask   (disjunction)
+ *                                                                      MI355_BITMAP_XOR  p ^ mask
+ *                                                                      MI355_BITMAP_ANDNOT  mask & ~p  (rows of mask that fail p)
+ * so a chain of predicates over several columns never needs a separate bitmap pass.
+ * bitmap_dev == NULL: COUNT-ONLY scan -- only hits_dev is produced, nothing is stored (the kernel then runs at the
+ * speed of the read stream alone; `SELECT count(*) WHERE ...`). */
+MI355_API int mi355_scan_combine_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int op, int64_t a, int64_t b,
+                                     int mask_op, const void *mask_dev, void *bitmap_dev, uint64_t *hits_dev);
 
 /* bitmap[i] = (v_i IN {keys[0..P-1]}) AND (and_mask ? and_mask[i] : 1), negated when `negate` != 0 (NOT IN).
  * 1 <= P <= 1024; keys outside [0, 2^c) match nothing.  c <= 16: bitset lookup, cost independent of P;
@@ -242,6 +253,9 @@ MI355_API int mi355_sharded_scan_range_dev(mi355_ctx *ctx, mi355_comm *comm, con
 /* name of the HIP kernel a given op dispatches to at width c ("scan_eq", "scan_range", "shared_scan",
  * "decompress", "pack"); returns NULL for unknown ops */
 MI355_API const char *mi355_kernel_name(const char *op, unsigned c);
+/* kernel family a shared scan of P keys at width c dispatches to (nothing is launched): "shared_lut_kernel" (P <= 8),
+ * "shared_lut_kernel(multi-pass)", "shared_wide_kernel", "shared_general_kernel" (tables do not fit in LDS) */
+MI355_API const char *mi355_shared_scan_kernel(mi355_ctx *ctx, unsigned c, unsigned P, int layout, int with_hits);
 /* rows per wave tile of the scan kernels at width c (shard boundaries should be multiples of it) */
 MI355_API uint64_t mi355_tile_values(unsigned c);
 

@@ -57,6 +57,9 @@ class _Oracle:
                                             C.c_void_p]
         L.oracle_gen_values.argtypes = [C.c_int, C.c_uint64, _sz, C.c_uint, C.c_uint64, C.c_void_p]
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_avx2_available.restype = C.c_int
+        L.oracle_avx2_scan_eq.restype = C.c_uint64
+        L.oracle_avx2_scan_eq.argtypes = [C.c_void_p, _sz, C.c_uint, C.c_int32, C.c_void_p, C.c_int]
         L.oracle_set_num_threads.argtypes = [C.c_int]
         self.L = L
 
@@ -98,6 +101,30 @@ class _Oracle:
         out = np.zeros((n + 7) // 8, dtype=np.uint8)
         hits = self.L.oracle_scan_eq(_ptr(packed), n, c, int(np.int32(np.uint32(key & 0xFFFFFFFF))), _ptr(out))
         return out, int(hits)
+
+    def avx2_available(self) -> bool:
+        return bool(self.L.oracle_avx2_available())
+
+    def scan_eq_avx2(self, packed: np.ndarray, n: int, c: int, key: int, threads: int = 1, reps: int = 1):
+        """oracle_avx2.c: the AVX2 (+ OpenMP when threads != 1; 0 = all cores) restatement of the reference's
+        scan_256_unrolled.  Needs 16 readable bytes past the payload (the reference's 256-byte pad).
+        -> (bitmap uint8[ceil(n/8)], hits, seconds per rep as a list)"""
+        import time
+
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        need = (n * c + 7) // 8 + 32
+        if packed.shape[0] < need:
+            p = np.zeros(need, dtype=np.uint8)
+            p[: packed.shape[0]] = packed
+            packed = p
+        out = np.zeros((n + 7) // 8, dtype=np.uint8)
+        key32 = int(np.int32(np.uint32(key & 0xFFFFFFFF)))
+        secs, hits = [], 0
+        for _ in range(max(1, reps)):
+            t0 = time.perf_counter()
+            hits = self.L.oracle_avx2_scan_eq(_ptr(packed), n, c, key32, _ptr(out), threads)
+            secs.append(time.perf_counter() - t0)
+        return out, int(hits), secs
 
     def scan_range(self, packed: np.ndarray, n: int, c: int, lo: int, hi: int):
         packed = self._padded(packed, n, c)

@@ -49,6 +49,7 @@ SYMBOLS = [
     ("mi355_shared_scan_eq_linear", _int, [_vp, _vp, _u64, C.c_uint, _vp, C.c_uint, _vp, _vp]),
     ("mi355_shared_scan_eq_dev", _int, [_vp, _vp, _u64, C.c_uint, _vp, C.c_uint, _int, _vp, _u64, _vp]),
     ("mi355_scan_where_dev", _int, [_vp, _vp, _u64, C.c_uint, _int, C.c_int64, C.c_int64, _vp, _vp, _vp]),
+    ("mi355_scan_combine_dev", _int, [_vp, _vp, _u64, C.c_uint, _int, C.c_int64, C.c_int64, _int, _vp, _vp, _vp]),
     ("mi355_scan_in_dev", _int, [_vp, _vp, _u64, C.c_uint, _vp, C.c_uint, _int, _vp, _vp, _vp]),
     ("mi355_bitmap_combine_dev", _int, [_vp, _int, _vp, _vp, _vp, _u64, _vp]),
     ("mi355_bitmap_count_dev", _int, [_vp, _vp, _u64, _vp]),
@@ -63,6 +64,7 @@ SYMBOLS = [
     ("mi355_sharded_scan_eq_dev", _int, [_vp, _vp, _vp, C.c_uint, _i32, _vp, _vp, _int, _vp, _vp]),
     ("mi355_sharded_scan_range_dev", _int, [_vp, _vp, _vp, C.c_uint, _u32, _u32, _vp, _vp, _int, _vp, _vp]),
     ("mi355_kernel_name", C.c_char_p, [C.c_char_p, C.c_uint]),
+    ("mi355_shared_scan_kernel", C.c_char_p, [_vp, C.c_uint, C.c_uint, _int, _int]),
     ("mi355_tile_values", _u64, [C.c_uint]),
 ]
 

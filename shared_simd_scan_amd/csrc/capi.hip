@@ -112,6 +112,9 @@ int launch(mi355_ctx *ctx, LaunchReq &r)
     r.max_blocks_per_cu = ctx->max_blocks_per_cu;
     r.dma_aux = ctx->dma_aux;
     r.scan_nt_stores = ctx->scan_nt_stores;
+    r.shared_vpl = ctx->shared_vpl;
+    r.scan_burst = ctx->scan_burst;
+    r.scan.flags = ctx->kernel_flags;
     r.scan.scratch = ctx->kernel_scratch;
     hipError_t e = kGroups[(r.c - 1) / 4](r);
     if (e != hipSuccess) return fail(MI355_E_HIP, "kernel launch (op %d, c=%u): %s", r.op, r.c, hipGetErrorString(e));
@@ -183,6 +186,9 @@ int mi355_ctx_create(int device, void *hip_stream, mi355_ctx **out)
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *s = getenv("MI355_MAX_BLOCKS_PER_CU")) c->max_blocks_per_cu = atoi(s);
     if (const char *s = getenv("MI355_DMA_AUX")) c->dma_aux = atoi(s);
+    if (const char *s = getenv("MI355_SCAN_BURST")) c->scan_burst = atoi(s);
+    if (const char *s = getenv("MI355_SHARED_VPL")) c->shared_vpl = atoi(s);
+    if (const char *s = getenv("MI355_KERNEL_FLAGS")) c->kernel_flags = (unsigned)atoi(s);
     // host-pointer flavours: the kernels write the hit counts here, straight into pinned (device-visible) host memory
     hipError_t e = hipHostMalloc((void **)&c->hits_scratch, kMaxKeys * sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&c->kernel_scratch, kScratchWords * sizeof(unsigned long long));
@@ -281,6 +287,12 @@ int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value)
         ctx->dma_aux = value;
     else if (!strcmp(name, "scan_nt_stores"))
         ctx->scan_nt_stores = value;
+    else if (!strcmp(name, "shared_vpl"))
+        ctx->shared_vpl = value;
+    else if (!strcmp(name, "scan_burst"))
+        ctx->scan_burst = value;
+    else if (!strcmp(name, "kernel_flags"))
+        ctx->kernel_flags = (unsigned)value;
     else
         return fail(MI355_E_INVALID, "unknown option %s", name);
     return MI355_OK;
@@ -560,21 +572,23 @@ int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n,
 }
 
 /* ---- predicates and bitmap consumers beyond the reference ---- */
-int mi355_scan_where_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int op, int64_t a, int64_t b,
-                         const void *and_mask_dev, void *bitmap_dev, uint64_t *hits_dev)
+int mi355_scan_combine_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int op, int64_t a, int64_t b,
+                           int mask_op, const void *mask_dev, void *bitmap_dev, uint64_t *hits_dev)
 {
     int rc = resolve(ctx);
     if (rc) return rc;
     CtxLock lk(ctx->mu);
     if ((rc = check_width(c))) return rc;
     if (op < MI355_CMP_EQ || op > MI355_CMP_NOT_BETWEEN) return fail(MI355_E_INVALID, "unknown comparison %d", op);
+    if (mask_op < MI355_BITMAP_AND || mask_op > MI355_BITMAP_ANDNOT) return fail(MI355_E_INVALID, "unknown mask op %d", mask_op);
+    if (!bitmap_dev && !hits_dev) return fail(MI355_E_INVALID, "bitmap_dev and hits_dev are both null: nothing to compute");
     if (n == 0) {
         if (hits_dev) HIP_TRY(hipMemsetAsync(hits_dev, 0, sizeof(uint64_t), ctx->stream));
         return MI355_OK;
     }
-    if (!packed_dev || !bitmap_dev) return fail(MI355_E_INVALID, "null device pointer");
-    if (((uintptr_t)packed_dev & 15) || ((uintptr_t)bitmap_dev & 15) || ((uintptr_t)and_mask_dev & 15))
-        return fail(MI355_E_INVALID, "packed_dev, bitmap_dev and and_mask_dev must be 16-byte aligned");
+    if (!packed_dev) return fail(MI355_E_INVALID, "null device pointer");
+    if (((uintptr_t)packed_dev & 15) || ((uintptr_t)bitmap_dev & 15) || ((uintptr_t)mask_dev & 15))
+        return fail(MI355_E_INVALID, "packed_dev, bitmap_dev and mask_dev must be 16-byte aligned");
     // every comparison is an inclusive range [lo, hi] over the domain [0, vmax], possibly negated
     const int64_t vmax = c == 32 ? 0xffffffffll : ((1ll << c) - 1);
     int64_t lo = 0, hi = vmax;
@@ -600,7 +614,8 @@ int mi355_scan_where_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, uns
     r.scan.out = (uint8_t *)bitmap_dev;
     r.scan.hits = (unsigned long long *)hits_dev;
     r.scan.nkeys = 1;
-    r.scan.and_mask = (const uint8_t *)and_mask_dev;
+    r.scan.and_mask = (const uint8_t *)mask_dev;
+    r.scan.mask_op = (uint32_t)mask_op;
     r.scan.invert = invert ? 0xffffffffu : 0u;
     if (empty) { // x - 1 <= 0 - ... : an impossible range: lo = 1, span = 0xffffffff - wraps; use lo > every value instead
         r.scan.key[0] = 0xffffffffu; // t = x - lo is never <= span 0 unless x == 0xffffffff, which needs c == 32 ...
@@ -615,6 +630,12 @@ int mi355_scan_where_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, uns
         r.scan.key[1] = (uint32_t)(hi - lo);
     }
     return launch(ctx, r);
+}
+
+int mi355_scan_where_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int op, int64_t a, int64_t b,
+                         const void *and_mask_dev, void *bitmap_dev, uint64_t *hits_dev)
+{
+    return mi355_scan_combine_dev(ctx, packed_dev, n, c, op, a, b, MI355_BITMAP_AND, and_mask_dev, bitmap_dev, hits_dev);
 }
 
 int mi355_scan_in_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const int32_t *keys_host, unsigned P,
@@ -865,9 +886,9 @@ const char *mi355_kernel_name(const char *op, unsigned c)
     static thread_local char buf[96];
     if (!op || c < 1 || c > 32) return nullptr;
     if (!strcmp(op, "scan_eq"))
-        snprintf(buf, sizeof buf, "mi355::scan_kernel<%u, 0, ", c);
+        snprintf(buf, sizeof buf, "mi355::scan_burst_kernel<%u, 0, ", c);
     else if (!strcmp(op, "scan_range"))
-        snprintf(buf, sizeof buf, "mi355::scan_kernel<%u, 1, ", c);
+        snprintf(buf, sizeof buf, "mi355::scan_burst_kernel<%u, 1, ", c);
     else if (!strcmp(op, "shared_scan"))
         snprintf(buf, sizeof buf, "mi355::shared_lut_kernel<%u, ", c);
     else if (!strcmp(op, "decompress"))
@@ -877,6 +898,27 @@ const char *mi355_kernel_name(const char *op, unsigned c)
     else
         return nullptr;
     return buf;
+}
+
+const char *mi355_shared_scan_kernel(mi355_ctx *ctx, unsigned c, unsigned P, int layout, int with_hits)
+{
+    if (resolve(ctx) != MI355_OK) return nullptr;
+    if (c < 1 || c > 32 || P < 1 || P > (unsigned)kMaxKeys) return nullptr;
+    if (P == 1) return "scan_burst_kernel";
+    CtxLock lk(ctx->mu);
+    LaunchReq r{};
+    int choice = -1;
+    unsigned long long dummy = 0;
+    r.op = kOpSharedScan;
+    r.c = c;
+    r.choice_out = &choice;
+    r.scan.n = 1;
+    r.scan.nkeys = P;
+    r.scan.layout = (uint32_t)layout;
+    r.scan.hits = with_hits ? &dummy : nullptr;
+    if (launch(ctx, r) != MI355_OK) return nullptr;
+    static const char *const names[] = {"shared_lut_kernel", "shared_lut_kernel(multi-pass)", "shared_wide_kernel", "shared_general_kernel"};
+    return choice >= 0 && choice < 4 ? names[choice] : nullptr;
 }
 
 uint64_t mi355_tile_values(unsigned c)

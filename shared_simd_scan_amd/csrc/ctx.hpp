@@ -17,6 +17,9 @@ struct mi355_ctx {
     int num_cus = 256;
     int max_blocks_per_cu = 0;
     int scan_nt_stores = -1; // -1: by bitmap size (see width_group.hip), 0 plain, 1 non-temporal
+    int shared_vpl = 0;  // 0: engine's choice
+    unsigned kernel_flags = 0; // experiment switches handed to the kernels (ScanArgs::flags)
+    int scan_burst = 0;  // 0: tiles per store burst by width; 1: one tile per burst
     int dma_aux = 18; // bits 0-3: policy of the HBM->LDS loads (2 = non-temporal: the column is streamed once);
                       // bit 4: non-temporal stores in decompress
     // Every entry point that touches the state below holds `mu` while it does (the host-pointer flavours from their

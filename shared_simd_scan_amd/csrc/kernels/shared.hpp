@@ -663,6 +663,24 @@ template <int C> struct WideLutGeom {
     }
 };
 
+// The next tile's DMA is issued BEFORE the tile's result stores, and vmcnt retires in issue order: once at most
+// `nstores` operations are outstanding, where `nstores` stores were issued after that DMA, the DMA has landed.  So the
+// top of the loop waits for a COUNT instead of draining the stores of the previous tile (a drain per tile left the
+// store queue empty during every lookup / transpose phase: stores in bursts of P between compute phases).
+__device__ __forceinline__ void wait_dma_behind_stores(uint32_t nstores)
+{
+    if (nstores >= 48)
+        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (nstores >= 32)
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (nstores >= 16)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (nstores >= 8)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int C, int AUX_, int VPL, int LAYOUT>
 __global__ __launch_bounds__(kBlockThreads) void shared_wide_kernel(ScanArgs a)
 {
@@ -728,14 +746,19 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide_kernel(ScanArgs a)
         }
     };
 
+    // store instructions a FULL tile issues after the next tile's DMA (a lower bound is what the wait needs):
+    // per-predicate: one per key; linear: at least one per 8-value group and 32-key round
+    const uint32_t stores_per_tile = LAYOUT == 0 ? P : (uint32_t)GROUPS * npass32;
+    uint32_t behind = 0; // stores issued after the DMA the next wait is for
     while (tile < tc.ntiles) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_dma_behind_stores(behind);
         uint32_t w[G::LANE_DWORDS];
         read_lane_data<C, VPL>(lds_wave, lane, w);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const uint64_t next = tile + stride;
         if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
         const bool full = tile < tc.nfull;
+        behind = (full && !(a.flags & 1u)) ? stores_per_tile : 0; // (a tail tile is a wave's last: nothing waits behind it)
         uint32_t xs[VPL];
         extract_all<C, VPL, 0, G::LANE_DWORDS>(w, xs);
         const int64_t left = (int64_t)(tc.n - tile * G::TILE_VALUES) - (int64_t)lane * VPL;

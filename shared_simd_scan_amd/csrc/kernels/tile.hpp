@@ -74,9 +74,20 @@ struct ScanArgs {
     uint32_t key[kMaxKeysPerPass]; // kModeEq: key[0]; kModeRange: key[0]=lo, key[1]=hi-lo; kModeShared: P<=8 keys
     uint32_t nkeys;            // P
     uint32_t layout;           // 0 per-predicate, 1 linear
-    const uint8_t *and_mask;   // kModeEq / kModeRange: optional bitmap ANDed into the result (conjunctions), may be null
+    const uint8_t *and_mask;   // kModeEq / kModeRange: optional bitmap combined with the result (conjunctions ...), may be null
     uint32_t invert;           // kModeEq / kModeRange: 0, or 0xffffffff to negate the predicate (!=, NOT BETWEEN)
+    uint32_t mask_op;          // how and_mask is combined: 0 result & mask, 1 result | mask, 2 result ^ mask, 3 mask & ~result
+                               // (kModeEq / kModeRange; in_kernel: AND only)
+    uint32_t flags;            // experiment switches (tuning aids): bit 0 = shared_wide_kernel drains its stores every tile
+    const uint8_t *packed2;    // scan2_kernel: the second column (same width, same n)
+    uint32_t key2[2];          // scan2_kernel: second predicate as (lo, hi - lo)
+    uint32_t invert2;          // scan2_kernel: negation word of the second predicate
+    unsigned long long *tile_state; // select_kernel: one {status, count} word per wave tile (decoupled look-back), zeroed per launch
+    uint64_t *rowids;          // select_kernel: ascending row ids out
+    uint64_t capacity;         // select_kernel: at most this many ids are written
+    uint64_t first_row;        // select_kernel: global row index of row 0
 };
+// `out` may be null in scan_kernel / scan2_kernel: count-only scan (hits without a bitmap).
 
 // ---- DMA: HBM -> LDS ---------------------------------------------------------------------------
 // One wave-instruction moves 64 x 16 B; the LDS destination is wave-uniform base + lane*16, the

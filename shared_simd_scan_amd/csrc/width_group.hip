@@ -1,6 +1,7 @@
 // width_group.hip -- instantiates the width-templated kernels for widths MI355_WLO..MI355_WHI and
 // exports one launcher per group.  Compiled 8 times (4 widths each) so the build parallelises.
 #include <atomic>
+#include <type_traits>
 
 #include "dispatch.hpp"
 #include "kernels.hpp"
@@ -67,13 +68,17 @@ template <int C, int VPL> bool lut8_fits(uint32_t P)
     return tables + lut_static_lds<C, VPL>() <= 160 * 1024;
 }
 
+// tiles per store burst of scan_burst_kernel at width C.  Same-process A/B on four MI355X boxes (tools/ab_opts.py
+// --opt scan_burst=..., 1e9 rows, launches back to back; profiles/r02_burst_*.txt): K = 4 is 0-4 % faster than K = 1 at
+// c = 9 (never slower), +1-2 % at c = 5, 6, 0-2 % at c = 10..16; it LOSES at c = 7 (0.171 against 0.149 ms) and c = 8
+// (0.184 against 0.177), is neutral at c <= 4, and -2 % at 64 values per lane (c >= 17).
+constexpr int burst_k(int c) { return (c == 5 || c == 6 || (c >= 9 && c <= 16)) ? 4 : 1; }
+
 template <int C, int MODE> void launch_scan(const LaunchReq &r)
 {
     constexpr int VPL = scan_vpl(C, MODE);
     using G = ScanGeom<C, VPL>;
-    static const int bpc = blocks_per_cu(scan_kernel<C, MODE, 2, VPL>);
     const uint64_t ntiles = (r.scan.n + G::TILE_VALUES - 1) / G::TILE_VALUES;
-    const unsigned grid = grid_for(ntiles, scan_bpc(bpc, G::TILE_BYTES, r), r.num_cus);
     // dma_aux: cache policy of the HBM->LDS stream; 2 (non-temporal: the column is read once) is the default.
     // Bitmap stores, measured with launches back to back (bench.py --store-policy, same box, 1e9 x 9 bit unless noted):
     // write-through (sc1) 0.201 ms, plain 0.207, non-temporal 0.216 -- dirty bitmap lines do not pile up in L2 to be
@@ -81,14 +86,68 @@ template <int C, int MODE> void launch_scan(const LaunchReq &r)
     // Bitmaps far beyond the 256 MiB Infinity Cache prefer non-temporal stores: 4e9 rows sc1 0.82 ms / nt 0.85,
     // 8e9 rows (1 GB of bitmap) 1.74 / 1.72.
     const int policy = r.scan_nt_stores < 0 ? (r.scan.n / 8 > (768ull << 20) ? 1 : 2) : r.scan_nt_stores; // 0 plain, 1 nt, 2 sc1
-    if (r.dma_aux == 0)
-        hipLaunchKernelGGL((scan_kernel<C, MODE, 0, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
-    else if (policy == 1)
-        hipLaunchKernelGGL((scan_kernel<C, MODE, 18, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
-    else if (policy == 2)
-        hipLaunchKernelGGL((scan_kernel<C, MODE, 34, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
+    auto go = [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        static const int bpcK = blocks_per_cu(scan_burst_kernel<C, MODE, 34, VPL, K>);
+        const dim3 grid(grid_for((ntiles + K - 1) / K, scan_bpc(bpcK, G::TILE_BYTES, r), r.num_cus));
+        if (r.dma_aux == 0)
+            hipLaunchKernelGGL((scan_burst_kernel<C, MODE, 0, VPL, K>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+        else if (policy == 1)
+            hipLaunchKernelGGL((scan_burst_kernel<C, MODE, 18, VPL, K>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+        else if (policy == 2)
+            hipLaunchKernelGGL((scan_burst_kernel<C, MODE, 34, VPL, K>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+        else
+            hipLaunchKernelGGL((scan_burst_kernel<C, MODE, 2, VPL, K>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+    };
+    // "scan_burst" option: 0 = the width's default, 1 = one tile per burst (scan_kernel's shape; A/B)
+    if (burst_k(C) > 1 && r.scan_burst != 1)
+        go(std::integral_constant<int, burst_k(C)>{});
     else
-        hipLaunchKernelGGL((scan_kernel<C, MODE, 2, VPL>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.scan);
+        go(std::integral_constant<int, 1>{});
+}
+
+// shared scan, P <= 8: LDS lookup table, one pass, deferred stores
+template <int C, int VPL> void launch_lut8(const LaunchReq &r, uint32_t P, bool linear)
+{
+    using G = ScanGeom<C, VPL>;
+    const uint64_t ntiles = (r.scan.n + G::TILE_VALUES - 1) / G::TILE_VALUES;
+    // measured (tools/tune_scan.hip, 1e9 x 9 bit, P = 8): one block per CU 0.41 ms, two 0.46, three 0.49
+    // (tools/sweep.py: c = 5, 2.5 KiB tiles, is the exception -- two blocks 0.30 ms against 0.37)
+    // The linear layout (word-wise transposition + LDS row stage) wants a second block per CU on random data:
+    // launches back to back, 1e9 x 9 bit, P = 8, random column 0.36-0.37 ms against 0.417 with one block; equal on
+    // the i % 8 column; per-predicate prefers one (0.35-0.38 against 0.37-0.40).
+    auto lut_bpc = [&](int occ) {
+        const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : ((G::TILE_BYTES < 4096 || linear) ? 2 : 1);
+        return want < occ ? want : occ;
+    };
+    static const int bpc_lin = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 1, false>);
+    static const int bpc_pp = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 0, false>);
+    const dim3 grid(grid_for(ntiles, lut_bpc(linear ? bpc_lin : bpc_pp), r.num_cus));
+    // one pass: write-through below 768 MiB of output, non-temporal beyond, as in launch_scan (launches back to
+    // back, P = 8: 1e8 rows sc1 0.046 ms / plain 0.047 / nt 0.049; 1e9 rows nt 0.353-0.383 / sc1 0.347-0.393 / plain 0.40)
+    const int spol = r.scan_nt_stores < 0 ? ((r.scan.n / 8) * P > (768ull << 20) ? 1 : 2) : r.scan_nt_stores; // 0 plain, 1 nt, 2 sc1
+    if (linear && spol == 1)
+        hipLaunchKernelGGL((shared_lut_kernel<C, 18, VPL, 1, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+    else if (linear && spol == 2)
+        hipLaunchKernelGGL((shared_lut_kernel<C, 34, VPL, 1, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+    else if (linear)
+        hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+    else if (spol == 1)
+        hipLaunchKernelGGL((shared_lut_kernel<C, 18, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+    else if (spol == 2)
+        hipLaunchKernelGGL((shared_lut_kernel<C, 34, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+    else
+        hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+}
+
+// which shared scans of <= 8 keys run with 128 values per lane by default (A/B on MI355X: see DESIGN.md section 3.1b)
+inline bool shared_lut_prefers_vpl128(int c, uint32_t P, bool linear)
+{
+    // launches back to back, 1e9 x 9 bit, same box (tools/sweep_p.py --vpl 64,128): per-predicate P = 2 0.296 -> 0.265 ms,
+    // P = 4 0.301 -> 0.272 (16-byte stores, 1 KiB per wave and key), P = 8 equal (0.349); linear LOSES (P = 2 0.244 ->
+    // 0.367, P = 8 0.365 -> 0.470: twice the row stage, one wave per SIMD)
+    (void)c;
+    return !linear && P <= 4;
 }
 
 template <int C> hipError_t launch_width(const LaunchReq &r)
@@ -102,12 +161,7 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         const uint64_t ntiles = (r.scan.n + G::TILE_VALUES - 1) / G::TILE_VALUES;
         const uint32_t P = r.scan.nkeys;
         const bool linear = r.scan.layout != 0;
-        // measured (tools/tune_scan.hip, 1e9 x 9 bit, P = 8): one block per CU 0.41 ms, two 0.46, three 0.49
-        // (tools/sweep.py: c = 5, 2.5 KiB tiles, is the exception -- two blocks 0.30 ms against 0.37)
-        // The linear layout (word-wise transposition + LDS row stage) wants a second block per CU on random data:
-        // launches back to back, 1e9 x 9 bit, P = 8, random column 0.36-0.37 ms against 0.417 with one block; equal on
-        // the i % 8 column; per-predicate prefers one (0.35-0.38 against 0.37-0.40).
-        auto lut_bpc = [&](int occ) {
+        auto lut_bpc = [&](int occ) { // multi-pass LUT kernel (see launch_lut8 for the one-pass kernels)
             const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : ((G::TILE_BYTES < 4096 || linear) ? 2 : 1);
             return want < occ ? want : occ;
         };
@@ -115,25 +169,20 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         // c = 9): 1e8 rows (100 MB of bitmaps) 0.0540 -> 0.0525 ms, 5e8 0.220 -> 0.214, 1e9 0.409 -> 0.372; c = 17: -1..-4 %.
         // Unlike the single bitmap of launch_scan, these outputs gain nothing from staying in the Infinity Cache.
         const bool nt_stores = r.scan_nt_stores < 0 ? (r.scan.n / 8) * P > (64ull << 20) : r.scan_nt_stores != 0;
+        if (r.choice_out) { // introspection (mi355_shared_scan_kernel): which kernel family would run, nothing is launched
+            *r.choice_out = P <= 8 ? 0 : (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) ? 1 : lut_fits<C, VPL>(P) ? 2 : 3;
+            break;
+        }
         if (P <= 8) { // LDS lookup table, one pass, deferred stores
-            static const int bpc_lin = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 1, false>);
-            static const int bpc_pp = blocks_per_cu(shared_lut_kernel<C, 2, VPL, 0, false>);
-            const dim3 grid(grid_for(ntiles, lut_bpc(linear ? bpc_lin : bpc_pp), r.num_cus));
-            // one pass: write-through below 768 MiB of output, non-temporal beyond, as in launch_scan (launches back to
-            // back, P = 8: 1e8 rows sc1 0.046 ms / plain 0.047 / nt 0.049; 1e9 rows nt 0.353-0.383 / sc1 0.347-0.393 / plain 0.40)
-            const int spol = r.scan_nt_stores < 0 ? ((r.scan.n / 8) * P > (768ull << 20) ? 1 : 2) : r.scan_nt_stores; // 0 plain, 1 nt, 2 sc1
-            if (linear && spol == 1)
-                hipLaunchKernelGGL((shared_lut_kernel<C, 18, VPL, 1, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
-            else if (linear && spol == 2)
-                hipLaunchKernelGGL((shared_lut_kernel<C, 34, VPL, 1, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
-            else if (linear)
-                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
-            else if (spol == 1)
-                hipLaunchKernelGGL((shared_lut_kernel<C, 18, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
-            else if (spol == 2)
-                hipLaunchKernelGGL((shared_lut_kernel<C, 34, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
-            else
-                hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 0, false>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+            // 128 values per lane (16-byte result stores, 1 KiB per wave and key) where the tile, the table and the linear
+            // stage fit in LDS and the registers hold 2 x 32 result dwords: c <= 12
+            if constexpr (C <= 12) {
+                if (r.shared_vpl == 128 || (r.shared_vpl == 0 && shared_lut_prefers_vpl128(C, P, linear))) {
+                    launch_lut8<C, 128>(r, P, linear);
+                    break;
+                }
+            }
+            launch_lut8<C, 64>(r, P, linear);
         } else if (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) {
             // linear rows of fewer than ~200 keys without hit counts: byte-entry tables, 16 output bytes per round
             // (measured, tools/sweep_p.py, 2.5e8 x 9 bit: P = 16 / 32 / 64 / 128 0.21 / 0.43 / 0.72 / 1.45 ms against

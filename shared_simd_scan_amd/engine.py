@@ -176,6 +176,20 @@ class ScanEngine:
                                          hits.data_ptr()))
         return bitmap, hits
 
+    def scan_combine(self, op: str, a: int, col: PackedColumn, b: int = 0, mask: Optional[torch.Tensor] = None,
+                     mask_op: str = "and", bitmap: Optional[torch.Tensor] = None, hits: Optional[torch.Tensor] = None,
+                     count_only: bool = False):
+        """scan_where with the earlier bitmap combined by AND / OR / XOR / ANDNOT (mask & ~p) inside the scan;
+        count_only=True stores no bitmap at all (returns (None, hits))."""
+        if bitmap is None and not count_only:
+            bitmap = self.alloc_bitmap(col.n)
+        if hits is None:
+            hits = torch.empty(1, dtype=torch.int64, device=self._dev)
+        check(lib().mi355_scan_combine_dev(self._ctx, col.data.data_ptr(), col.n, col.c, self._CMP[op], int(a), int(b),
+                                           self._BOP[mask_op], mask.data_ptr() if mask is not None else None,
+                                           None if count_only else bitmap.data_ptr(), hits.data_ptr()))
+        return (None if count_only else bitmap), hits
+
     def scan_in(self, keys: Sequence[int], col: PackedColumn, negate: bool = False,
                 and_mask: Optional[torch.Tensor] = None, bitmap: Optional[torch.Tensor] = None,
                 hits: Optional[torch.Tensor] = None):

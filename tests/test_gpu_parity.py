@@ -327,6 +327,35 @@ def test_shared_scan_wide_and_many_keys(O, eng, c, P, layout):
     assert np.array_equal(hits.cpu().numpy().astype(np.uint64), ohits)
 
 
+@pytest.mark.parametrize("c,P", [(32, 1024), (25, 900), (31, 705)])
+@pytest.mark.parametrize("layout", ["per_predicate", "linear"])
+@pytest.mark.parametrize("count", [True, False])
+def test_shared_scan_compare_chain_fallback(O, eng, L, c, P, layout, count):
+    """key counts whose lookup tables do not fit in LDS run on shared_general_kernel (compare chain): full tiles, the
+    linear transpose / store path and the ragged tail, with and without hit counts"""
+    lay = 1 if layout == "linear" else 0
+    assert L.mi355_shared_scan_kernel(eng._ctx, c, P, lay, 1 if count else 0) == b"shared_general_kernel"
+    assert L.mi355_shared_scan_kernel(eng._ctx, 9, 64, 0, 1) == b"shared_wide_kernel"
+    assert L.mi355_shared_scan_kernel(eng._ctx, 9, 8, 1, 0) == b"shared_lut_kernel"
+    n = 2 * 4096 + 77
+    vals, col = make_column(O, eng, n, c, 5100 + c + P)
+    rng = np.random.default_rng(P + c)
+    keys = [int(vals[int(i)]) for i in rng.integers(0, n, size=P)]
+    keys[7] = keys[3]
+    keys32 = [k if k < 2 ** 31 else k - 2 ** 32 for k in keys]
+    out, hits = eng.shared_scan(keys32, col, layout=layout, hits=None if count else False)
+    v = vals.astype(np.int64)
+    nb = (n + 7) // 8
+    per_key = np.stack([np_bitmap(v == k) for k in keys])
+    got = out.cpu().numpy()
+    if layout == "per_predicate":
+        assert np.array_equal(got[:, :nb], per_key)
+    else:
+        assert np.array_equal(got.reshape(nb, P), per_key.T)
+    if count:
+        assert np.array_equal(hits.cpu().numpy(), np.array([int((v == k).sum()) for k in keys]))
+
+
 def test_out_of_range_keys_never_match(O, eng):
     """SURVEY 8c hazard 5: keys 515, 1027, 65539, -1 on a 9-bit column -> no hits, zero bitmap."""
     import torch
@@ -587,6 +616,55 @@ def test_scan_where_all_comparisons(O, eng, c, n):
     expect = (v >= a) & (v <= b)
     assert np.array_equal(bm.cpu().numpy(), np_bitmap(expect)) and int(hits.item()) == int(expect.sum())
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("c", [1, 3, 5, 7, 9, 12, 16, 17, 21, 32])
+@pytest.mark.parametrize("n", [8192 * 9 + 77, 4096 * 41 + 5, 1000, 8192 * 64])
+def test_fused_mask_ops_and_count_only(O, eng, c, n):
+    """mi355_scan_combine_dev: the earlier bitmap combined inside the scan by AND / OR / XOR / ANDNOT, and the count-only
+    form (no bitmap stored), against numpy on the decoded values; every width class (table decode, 128 and 64 values
+    per lane), sizes with several chunks per wave and a ragged last tile.  Repeated, so that an ordering bug between the
+    mask's LDS-DMA and its use would show (it did, once: c <= 3, 29 launches of 30)."""
+    vals, col = make_column(O, eng, n, c, 9100 + c + n)
+    v = vals.astype(np.int64)
+    vmax = (1 << c) - 1
+    a = int(vals[5])
+    first = v <= (vmax // 2)
+    mask, _ = eng.scan_where("<=", vmax // 2, col)
+    p = v >= a
+    for rep in range(4):
+        for mop, expect in (("and", p & first), ("or", p | first), ("xor", p ^ first), ("andnot", first & ~p)):
+            bm, hits = eng.scan_combine(">=", a, col, mask=mask, mask_op=mop)
+            assert np.array_equal(bm.cpu().numpy(), np_bitmap(expect)), (mop, c, n, rep)
+            assert int(hits.item()) == int(expect.sum())
+            none, hits = eng.scan_combine(">=", a, col, mask=mask, mask_op=mop, count_only=True)
+            assert none is None and int(hits.item()) == int(expect.sum()), (mop, c, n, "count only")
+        none, hits = eng.scan_combine("!=", a, col, count_only=True)
+        assert int(hits.item()) == int((v != a).sum())
+        none, hits = eng.scan_combine("between", a, col, b=vmax, count_only=True)
+        assert int(hits.item()) == int(p.sum())
+
+
+@pytest.mark.parametrize("c", [5, 6, 9, 12, 16])
+def test_one_tile_per_burst_option_agrees(O, eng, c):
+    """widths whose default is 4 tiles per store burst (burst_k): the K = 1 build of the same kernel gives the same bytes"""
+    n = 8192 * 37 + 123
+    vals, col = make_column(O, eng, n, c, 9300 + c)
+    key = int(vals[11])
+    try:
+        eng.set_option("scan_burst", 0)
+        bm4, h4 = eng.scan(key, col)
+        r4, hr4 = eng.scan_range(1, (1 << c) // 2, col)
+        eng.set_option("scan_burst", 1)
+        bm1, h1 = eng.scan(key, col)
+        r1, hr1 = eng.scan_range(1, (1 << c) // 2, col)
+    finally:
+        eng.set_option("scan_burst", 0)
+    obm, ohits = O.scan_eq(col.data.cpu().numpy(), n, c, key)
+    assert np.array_equal(bm4.cpu().numpy(), obm) and np.array_equal(bm1.cpu().numpy(), obm)
+    assert int(h4.item()) == ohits == int(h1.item())
+    orb, orh = O.scan_range(col.data.cpu().numpy(), n, c, 1, (1 << c) // 2)
+    assert np.array_equal(r4.cpu().numpy(), orb) and np.array_equal(r1.cpu().numpy(), orb) and int(hr4.item()) == orh == int(hr1.item())
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 127, 128, 1000, 16384, 16385, 100_003, 1_000_003])

@@ -56,6 +56,37 @@ def test_scan_eq_matches_reference(O, golden, w, n):
 
 @pytest.mark.parametrize("w", GOLDEN_WIDTHS)
 @pytest.mark.parametrize("n", GOLDEN_SIZES)
+@pytest.mark.parametrize("threads", [1, 3])
+def test_avx2_restatement_matches_reference(O, golden, w, n, threads):
+    """oracle_avx2.c (the CPU baseline of bench.py on hosts without oracle/_ref) against the reference's scan_128 vectors:
+    first n bits always; the whole buffer and the hit count whenever the reference's variants agree (key != 0)."""
+    if not O.avx2_available():
+        pytest.skip("host CPU has no AVX2")
+    g = golden[w]
+    packed = g[f"n{n}_packed"]
+    for key, ref_buf, ref_hits in zip(g[f"n{n}_keys"], g[f"n{n}_scan128"], g[f"n{n}_scan128_hits"]):
+        out, hits, _ = O.scan_eq_avx2(packed, n, w, int(key), threads=threads)
+        assert np.array_equal(bits(out, n), bits(ref_buf, n))
+        assert hits == bits(ref_buf, n).sum()
+        if key != 0:
+            assert np.array_equal(out, ref_buf[: out.shape[0]]) and hits == ref_hits
+
+
+@pytest.mark.parametrize("c", list(range(1, 33)))
+def test_avx2_restatement_matches_scalar_oracle_all_widths(O, c):
+    """every width (c > 25 takes the scalar path inside), ragged sizes, keys at the ends of the domain and outside it"""
+    rng = np.random.default_rng(4000 + c)
+    for n in (1, 8, 31, 33, 255, 257, 4101, 70_001):
+        vals = rng.integers(0, 1 << c, size=n, dtype=np.uint64).astype(np.uint32)
+        packed = O.pack(vals, c)
+        for key in (int(vals[0]), int(vals[n // 2]), 0, (1 << c) - 1, (1 << c) + 1 if c < 31 else 5, -1):
+            a, ha = O.scan_eq(packed, n, c, key)
+            b, hb, _ = O.scan_eq_avx2(packed, n, c, key, threads=2)
+            assert np.array_equal(a, b) and ha == hb, (c, n, key)
+
+
+@pytest.mark.parametrize("w", GOLDEN_WIDTHS)
+@pytest.mark.parametrize("n", GOLDEN_SIZES)
 @pytest.mark.parametrize("P", [1, 3, 8])
 def test_shared_scan_matches_reference(O, golden, w, n, P):
     g = golden[w]

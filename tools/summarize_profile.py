@@ -24,7 +24,7 @@ def _sha():
 
 def main():
     src, workload, tag, rows, bits = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
-    kmatch = {"scan_eq": "scan_kernel<%d, 0," % bits, "scan_range": "scan_kernel<%d, 1," % bits,
+    kmatch = {"scan_eq": "scan_burst_kernel<%d, 0," % bits, "scan_range": "scan_burst_kernel<%d, 1," % bits,
               "shared_scan": "shared_lut_kernel<%d," % bits, "decompress": "decompress_kernel<%d," % bits}[workload]
     stats = None
     newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1:]  # noqa: E731  (re-runs leave older files)

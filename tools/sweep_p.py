@@ -18,6 +18,9 @@ def main():
     ap.add_argument("--layouts", default="per_predicate,linear")
     ap.add_argument("--nts", default="-1")
     ap.add_argument("--bpc", default="0", help="max_blocks_per_cu values to sweep (0 = the engine's default)")
+    ap.add_argument("--vpl", default="0", help="shared_vpl values to sweep (0 = the engine's choice, 64, 128)")
+    ap.add_argument("--burst", type=int, default=1, help="launches per timed region (back to back: sustained rate)")
+    ap.add_argument("--hits", default="1,0", help="1: with hit counts, 0: without")
     args = ap.parse_args()
     import torch
 
@@ -35,10 +38,13 @@ def main():
             else:
                 out = torch.empty(nb * P, dtype=torch.uint8, device="cuda")
             hits = torch.zeros(P, dtype=torch.int64, device="cuda")
-            for nts, bpc in [(int(x), int(y)) for x in args.nts.split(",") for y in args.bpc.split(",")]:
+            for nts, bpc, vpl in [(int(x), int(y), int(z)) for x in args.nts.split(",") for y in args.bpc.split(",")
+                                  for z in args.vpl.split(",")]:
                 eng.set_option("scan_nt_stores", nts)
                 eng.set_option("max_blocks_per_cu", bpc)
-                for with_hits in (True, False):
+                if args.vpl != "0":
+                    eng.set_option("shared_vpl", vpl)
+                for with_hits in [bool(int(h)) for h in args.hits.split(",")]:
                     fn = lambda: eng.shared_scan(keys, col, layout=layout, out=out, hits=hits if with_hits else False)  # noqa: E731
                     for _ in range(2):
                         fn()
@@ -47,14 +53,15 @@ def main():
                     for _ in range(args.reps):
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                        fn()
+                        for _ in range(args.burst):
+                            fn()
                         e1.record()
                         e1.synchronize()
-                        ms.append(e0.elapsed_time(e1))
+                        ms.append(e0.elapsed_time(e1) / args.burst)
                     ms.sort()
                     med = ms[len(ms) // 2]
                     nbytes = n * c / 8 + n / 8 * P
-                    print(f"P={P:4d} {layout:13s} nts={nts:2d} bpc={bpc} hits={int(with_hits)}  med {med:8.4f} ms  {nbytes / med / 1e6:7.1f} GB/s  "
+                    print(f"P={P:4d} {layout:13s} nts={nts:2d} bpc={bpc} vpl={vpl:3d} hits={int(with_hits)}  med {med:8.4f} ms  {nbytes / med / 1e6:7.1f} GB/s  "
                           f"{n * P / med * 1e3:.3e} predicate-evals/s", flush=True)
             del out
             torch.cuda.empty_cache()
