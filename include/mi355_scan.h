@@ -191,6 +191,16 @@ MI355_API int mi355_scan_combine_dev(mi355_ctx *ctx, const void *packed_dev, uin
 MI355_API int mi355_scan_in_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const int32_t *keys_host, unsigned P,
                                 int negate, const void *and_mask_dev, void *bitmap_dev, uint64_t *hits_dev);
 
+/* Fused scan + selection vector: rowids_dev receives first_row + i, ascending, for every row i with
+ *   mask_dev ? COMBINE(p[i], mask[i]) : p[i]        (p, mask_op as in mi355_scan_combine_dev)
+ * (at most `capacity` ids are written), count_dev the number of such rows -- ONE launch, and no bitmap ever goes to HBM
+ * (the chain scan -> mi355_bitmap_to_rowids_dev writes the bitmap once and reads it twice).  If the in-launch look-back
+ * ever gave up waiting (it cannot while the device makes progress) count_dev reads UINT64_MAX.  Not capturable into a
+ * graph when the context's workspace has to grow (first call for a larger column). */
+MI355_API int mi355_scan_select_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int op, int64_t a, int64_t b,
+                                    int mask_op, const void *mask_dev, uint64_t first_row, uint64_t *rowids_dev, uint64_t capacity,
+                                    uint64_t *count_dev);
+
 #define MI355_BITMAP_AND 0
 #define MI355_BITMAP_OR 1
 #define MI355_BITMAP_XOR 2

@@ -572,6 +572,41 @@ int mi355_shared_scan_eq_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n,
 }
 
 /* ---- predicates and bitmap consumers beyond the reference ---- */
+// every comparison is an inclusive range [lo, hi] over the column's domain [0, 2^c), possibly negated: fills
+// key[0] = lo, key[1] = hi - lo and the negation word of a scan request
+static void fill_predicate(ScanArgs &sa, unsigned c, int op, int64_t a, int64_t b)
+{
+    const int64_t vmax = c == 32 ? 0xffffffffll : ((1ll << c) - 1);
+    int64_t lo = 0, hi = vmax;
+    bool invert = false, empty = false;
+    switch (op) {
+    case MI355_CMP_EQ: lo = hi = a; break;
+    case MI355_CMP_NE: lo = hi = a; invert = true; break;
+    case MI355_CMP_LT: hi = a - 1; break;
+    case MI355_CMP_LE: hi = a; break;
+    case MI355_CMP_GT: lo = a + 1; break;
+    case MI355_CMP_GE: lo = a; break;
+    case MI355_CMP_BETWEEN: lo = a; hi = b; break;
+    case MI355_CMP_NOT_BETWEEN: lo = a; hi = b; invert = true; break;
+    }
+    if (lo < 0) lo = 0;
+    if (hi > vmax) hi = vmax;
+    if (lo > hi) empty = true; // matches nothing (or, negated, everything)
+    sa.invert = invert ? 0xffffffffu : 0u;
+    if (empty) { // lo above every value: t = x - lo is never <= span 0 unless x == 0xffffffff, which needs c == 32 ...
+        sa.key[0] = 0xffffffffu;
+        sa.key[1] = 0;
+        if (c == 32) { // ... so fold the empty case into the negation flag on the full range
+            sa.key[0] = 0;
+            sa.key[1] = 0xffffffffu;
+            sa.invert = invert ? 0u : 0xffffffffu;
+        }
+    } else {
+        sa.key[0] = (uint32_t)lo;
+        sa.key[1] = (uint32_t)(hi - lo);
+    }
+}
+
 int mi355_scan_combine_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int op, int64_t a, int64_t b,
                            int mask_op, const void *mask_dev, void *bitmap_dev, uint64_t *hits_dev)
 {
@@ -589,23 +624,6 @@ int mi355_scan_combine_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, u
     if (!packed_dev) return fail(MI355_E_INVALID, "null device pointer");
     if (((uintptr_t)packed_dev & 15) || ((uintptr_t)bitmap_dev & 15) || ((uintptr_t)mask_dev & 15))
         return fail(MI355_E_INVALID, "packed_dev, bitmap_dev and mask_dev must be 16-byte aligned");
-    // every comparison is an inclusive range [lo, hi] over the domain [0, vmax], possibly negated
-    const int64_t vmax = c == 32 ? 0xffffffffll : ((1ll << c) - 1);
-    int64_t lo = 0, hi = vmax;
-    bool invert = false, empty = false;
-    switch (op) {
-    case MI355_CMP_EQ: lo = hi = a; break;
-    case MI355_CMP_NE: lo = hi = a; invert = true; break;
-    case MI355_CMP_LT: hi = a - 1; break;
-    case MI355_CMP_LE: hi = a; break;
-    case MI355_CMP_GT: lo = a + 1; break;
-    case MI355_CMP_GE: lo = a; break;
-    case MI355_CMP_BETWEEN: lo = a; hi = b; break;
-    case MI355_CMP_NOT_BETWEEN: lo = a; hi = b; invert = true; break;
-    }
-    if (lo < 0) lo = 0;
-    if (hi > vmax) hi = vmax;
-    if (lo > hi) empty = true; // matches nothing (or, negated, everything)
     LaunchReq r{};
     r.op = kOpScanRange;
     r.c = c;
@@ -616,19 +634,55 @@ int mi355_scan_combine_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, u
     r.scan.nkeys = 1;
     r.scan.and_mask = (const uint8_t *)mask_dev;
     r.scan.mask_op = (uint32_t)mask_op;
-    r.scan.invert = invert ? 0xffffffffu : 0u;
-    if (empty) { // x - 1 <= 0 - ... : an impossible range: lo = 1, span = 0xffffffff - wraps; use lo > every value instead
-        r.scan.key[0] = 0xffffffffu; // t = x - lo is never <= span 0 unless x == 0xffffffff, which needs c == 32 ...
-        r.scan.key[1] = 0;
-        if (c == 32) { // ... so fold the empty case into the negation flag on the full range
-            r.scan.key[0] = 0;
-            r.scan.key[1] = 0xffffffffu;
-            r.scan.invert = invert ? 0u : 0xffffffffu;
-        }
-    } else {
-        r.scan.key[0] = (uint32_t)lo;
-        r.scan.key[1] = (uint32_t)(hi - lo);
+    fill_predicate(r.scan, c, op, a, b);
+    return launch(ctx, r);
+}
+
+int mi355_scan_select_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int op, int64_t a, int64_t b, int mask_op,
+                          const void *mask_dev, uint64_t first_row, uint64_t *rowids_dev, uint64_t capacity, uint64_t *count_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    CtxLock lk(ctx->mu);
+    if ((rc = check_width(c))) return rc;
+    if (op < MI355_CMP_EQ || op > MI355_CMP_NOT_BETWEEN) return fail(MI355_E_INVALID, "unknown comparison %d", op);
+    if (mask_op < MI355_BITMAP_AND || mask_op > MI355_BITMAP_ANDNOT) return fail(MI355_E_INVALID, "unknown mask op %d", mask_op);
+    if (!count_dev) return fail(MI355_E_INVALID, "count_dev is null");
+    if ((rc = bind(ctx))) return rc;
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(uint64_t), ctx->stream));
+        return MI355_OK;
     }
+    if (!packed_dev || (!rowids_dev && capacity)) return fail(MI355_E_INVALID, "null device pointer");
+    if (((uintptr_t)packed_dev & 15) || ((uintptr_t)mask_dev & 15))
+        return fail(MI355_E_INVALID, "packed_dev and mask_dev must be 16-byte aligned");
+    // one state word per chunk of tiles (decoupled look-back), zeroed in front of the launch
+    const uint64_t tile_values = 64 * (uint64_t)scan_vpl((int)c, kModeRange);
+    const uint64_t ntiles = (n + tile_values - 1) / tile_values;
+    const uint64_t nchunks = (ntiles + select_tiles((int)c) - 1) / select_tiles((int)c);
+    if (ctx->rowid_ws_entries < nchunks) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->rowid_ws) HIP_TRY(hipFree(ctx->rowid_ws));
+        ctx->rowid_ws = nullptr;
+        ctx->rowid_ws_entries = 0;
+        HIP_TRY(hipMalloc((void **)&ctx->rowid_ws, nchunks * sizeof(unsigned long long)));
+        ctx->rowid_ws_entries = nchunks;
+    }
+    HIP_TRY(hipMemsetAsync(ctx->rowid_ws, 0, nchunks * sizeof(unsigned long long), ctx->stream));
+    LaunchReq r{};
+    r.op = kOpSelect;
+    r.c = c;
+    r.scan.packed = (const uint8_t *)packed_dev;
+    r.scan.n = n;
+    r.scan.hits = (unsigned long long *)count_dev;
+    r.scan.nkeys = 1;
+    r.scan.and_mask = (const uint8_t *)mask_dev;
+    r.scan.mask_op = (uint32_t)mask_op;
+    r.scan.tile_state = ctx->rowid_ws;
+    r.scan.rowids = rowids_dev;
+    r.scan.capacity = capacity;
+    r.scan.first_row = first_row;
+    fill_predicate(r.scan, c, op, a, b);
     return launch(ctx, r);
 }
 

@@ -8,7 +8,7 @@
 
 namespace mi355 {
 
-enum Op { kOpScanEq = 0, kOpScanRange = 1, kOpSharedScan = 2, kOpDecompress = 3, kOpScanIn = 4 };
+enum Op { kOpScanEq = 0, kOpScanRange = 1, kOpSharedScan = 2, kOpDecompress = 3, kOpScanIn = 4, kOpSelect = 5 };
 
 struct LaunchReq {
     int op;

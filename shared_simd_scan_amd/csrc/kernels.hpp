@@ -18,6 +18,7 @@
 //   shared_wide_kernel     shared scan for P > 8: dword-entry tables, 32 predicates per lookup
 //   shared_general_kernel  shared scan by compare chain, for key counts whose tables do not fit in LDS
 //   in_kernel              IN-list scan (one bitmap for a key set)
+//   select_kernel          predicate -> ascending row ids in one launch (decoupled look-back over chunk counts), no bitmap
 //   decompress_kernel      packed -> int32, lane per value
 //   pack_kernel            packer and synthetic column generators
 //   bitmap_kernel, rowid_* bitmap combine / count, selection vector
@@ -35,6 +36,7 @@
 #include "kernels/scan.hpp"
 #include "kernels/shared.hpp"
 #include "kernels/in_list.hpp"
+#include "kernels/select.hpp"
 #include "kernels/bitmap.hpp"
 #include "kernels/decompress.hpp"
 #include "kernels/pack.hpp"

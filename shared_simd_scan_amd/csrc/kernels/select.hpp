@@ -1,0 +1,338 @@
+// kernels/select.hpp -- select_kernel: predicate scan -> ascending row ids in ONE launch, no bitmap in HBM.
+// Part of kernels.hpp (gfx950 only).
+#pragma once
+
+#include "scan.hpp"
+
+namespace mi355 {
+
+// ---- fused scan + selection vector ("fused so the bitmap need not round-trip HBM") --------------------
+// The chain scan -> bitmap -> mi355_bitmap_to_rowids_dev writes the bitmap, reads it twice (count, expand) and runs
+// four launches.  Here a wave decodes tiles exactly as scan_burst_kernel does, parks the bitmap words of a CHUNK of
+// select_tiles(c) consecutive tiles in LDS (16 KiB per wave = 128 Ki rows at 128 values per lane; registers would force
+// the tile loop to be unrolled 16 times -- a runtime index into a register array goes to scratch memory) and turns them
+// into row ids on the spot.  The only cross-chunk information an id needs is the number of hits in all
+// earlier chunks: a decoupled look-back over per-chunk state words supplies it inside the launch.
+//
+//   state[q] = { status : 2, value : 62 }   status 0 = nothing yet, 1 = value is chunk q's own count (aggregate),
+//                                           2 = value is the count of chunks 0..q (inclusive prefix)
+//   wave of chunk q:  publish {1, count_q}; read the state of the 1024 chunks in front of it in one poll (16 per
+//   lane, nearest first), add aggregates until a chunk that already knows its inclusive prefix; publish
+//   {2, prefix + count_q}.  The persistent grid has ~1024 waves in flight, each on one chunk, so one poll normally
+//   reaches a finished chunk; the look-back costs a few microseconds per chunk of ~30 us.  (A look-back per 8 Ki-row
+//   tile would walk the same 1024 in-flight tiles 64 at a time, ~16 dependent polls per 2 us tile.)
+//
+// Visibility across CUs / XCDs (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
+// every state word is ONE naturally aligned 8-byte granule that carries its own tag, written by one agent-scope
+// relaxed atomic store (write-through, `sc1`) and polled with agent-scope relaxed atomic loads (`sc1`: served past
+// the CU's L1) -- there is no flag / payload ordering to get wrong.  The words are zeroed by a memset node in front
+// of every launch.  Forward progress: the grid is persistent and fully resident (one block per CU by LDS) and every
+// wave takes its chunks in ascending order, so the wave a look-back waits for is running or done; every spin is
+// bounded (kSelectSpinLimit polls) and a wave that gives up flags the result (count = ~0) instead of hanging the
+// device.
+//
+// Expansion, one 32-row word of every lane (2048 rows of the tile... in lane-major row order: lane l owns rows
+// [VPL l, VPL l + VPL) of a tile) at a time: writing ids lane by lane would make every store instruction touch 64
+// different lines at high selectivity, so the lanes drop their 16-bit in-tile row offsets into a per-wave LDS stage at
+// the positions a wave prefix sum of the lane counts gives, then the wave copies the stage out with consecutive lanes
+// writing consecutive ids (512 B per store instruction).  Ids must ascend, and lane l's rows all precede lane l+1's:
+// the words of a tile are therefore expanded lane-major, i.e. all WORDS words of a lane form ONE run of the prefix sum.
+// tiles per chunk (64 Ki rows where it fits): the wave's LDS -- tile + mask image + half-tile id stage + the parked words
+// of TWO chunks -- must let four waves share the CU's 160 KiB
+constexpr int select_tiles(int c) { return c > 16 ? 16 : (c >= 14 ? 4 : 8); }
+constexpr int kSelectWindow = 16;         // state words per lane and poll (1024 per wave)
+constexpr uint32_t kSelectSpinLimit = 1u << 20;
+constexpr unsigned long long kSelectValueMask = (1ull << 62) - 1ull;
+
+template <int C, int MODE, int VPL>
+__global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
+{
+    using G = ScanGeom<C, VPL>;
+    static_assert(MODE == kModeEq || MODE == kModeRange, "MODE");
+    constexpr int WORDS = G::WORDS;
+    constexpr int K = select_tiles(C);
+    constexpr int HALF = G::TILE_VALUES / 2; // ids one expansion pass can stage (the rows of 32 lanes)
+    constexpr int AUX = 2; // the column is streamed once: non-temporal DMA
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t mlds[kWavesPerBlock][1024];
+    __shared__ __attribute__((aligned(16))) uint16_t stage[kWavesPerBlock][HALF];
+    __shared__ __attribute__((aligned(16))) uint32_t parked[kWavesPerBlock][2][K][64 * WORDS]; // bitmap words of two chunks
+    constexpr int LK = narrow_k<C>();
+    __shared__ __attribute__((aligned(16))) uint8_t nlut[LK ? (1 << (LK * C)) : 16];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    uint8_t *mlds_wave = mlds[wave];
+    uint16_t *st = stage[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t nchunks = (tc.ntiles + K - 1) / K;
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t chunk = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+
+    const uint32_t key[2] = {a.key[0], a.key[1]};
+    const uint8_t *const mask = a.and_mask;
+    const uint32_t mop = a.mask_op, inv = a.invert;
+    auto combine = [mop](uint32_t r, uint32_t m) -> uint32_t {
+        return mop == 0 ? (r & m) : mop == 1 ? (r | m) : mop == 2 ? (r ^ m) : (m & ~r);
+    };
+    unsigned long long *const state = a.tile_state;
+
+    auto issue_tile = [&](uint64_t t) {
+        // the tile's mask bytes first (a full tile: one 1 KiB / 512 B image), then the packed tile: the wait at the top
+        // of the tile's iteration drains both
+        if (mask && t < tc.nfull) {
+            if (lane * 16 < G::BITMAP_BYTES)
+                __builtin_amdgcn_global_load_lds(MI355_GPTR(mask + t * G::BITMAP_BYTES + lane * 16), MI355_LPTR(mlds_wave), 16, 0, 0);
+        }
+        tc.template issue<AUX>(a.packed, t, lds_wave, lane);
+    };
+
+    if (chunk < nchunks) issue_tile(chunk * K);
+    if constexpr (LK > 0) {
+        constexpr uint32_t fmask = (1u << C) - 1u;
+        for (uint32_t e = threadIdx.x; e < (1u << (LK * C)); e += kBlockThreads) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < LK; j++) {
+                const uint32_t f = (e >> (j * C)) & fmask;
+                const bool hit = (MODE == kModeRange) ? (f - key[0]) <= key[1] : f == key[0];
+                m |= (hit ? 1u : 0u) << j;
+            }
+            nlut[e] = (uint8_t)m;
+        }
+        __syncthreads();
+    }
+
+    bool gave_up = false;
+
+    // hits in all chunks before q (decoupled look-back), then publishes q's inclusive prefix
+    auto resolve = [&](uint64_t q, unsigned long long q_hits) -> unsigned long long {
+        if (q == 0) return 0ull; // chunk 0 published its inclusive prefix right away
+        unsigned long long before = 0;
+        int64_t pos = (int64_t)q - 1; // nearest chunk of the poll; group k, lane l looks at chunk pos - 64 k - l
+        uint32_t spins = 0;
+        bool done = false;
+        while (!done) {
+            // one poll = kSelectWindow loads of 64 CONSECUTIVE state words each (512 B, four lines per instruction; a
+            // lane reading its own run of 16 words would touch 1024 lines per poll), all issued before the first is used
+            unsigned long long s[kSelectWindow];
+#pragma unroll
+            for (int k = 0; k < kSelectWindow; k++) {
+                const int64_t i = pos - 64 * k - lane;
+                // chunks before the column: "prefix of nothing" = inclusive 0
+                s[k] = i >= 0 ? __hip_atomic_load(state + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+            }
+            unsigned long long acc = 0;
+            bool retry = false;
+#pragma unroll
+            for (int k = 0; k < kSelectWindow; k++) {
+                if (!done && !retry) { // wave-uniform
+                    const uint32_t status = (uint32_t)(s[k] >> 62);
+                    const unsigned long long fmask = __ballot(status == 2);
+                    const unsigned long long bmask = __ballot(status == 0);
+                    // the nearest chunk that knows its inclusive prefix ends the walk; every chunk nearer than it must
+                    // at least have published its own count
+                    const int stop = fmask ? __builtin_ctzll(fmask) : 64;
+                    const unsigned long long need = stop >= 63 ? ~0ull : ((2ull << stop) - 1ull);
+                    if (bmask & need) {
+                        retry = true; // what was summed so far stays valid: resume at this group
+                        pos -= 64 * k;
+                    } else {
+                        if (lane <= stop) acc += s[k] & kSelectValueMask;
+                        done = stop < 64;
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            before += acc;
+            if (retry) {
+                if (++spins > kSelectSpinLimit) {
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            } else if (!done) {
+                pos -= 64 * kSelectWindow;
+            }
+        }
+        if (lane == 0)
+            __hip_atomic_store(state + q, (2ull << 62) | ((before + q_hits) & kSelectValueMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return before;
+    };
+
+    // ids of chunk q (its words parked in `pk`), tile by tile.  Sparse tiles (<= 64 ids: the usual case of a selective
+    // predicate) write their few ids straight from the lanes; denser ones go through the LDS stage.
+    auto expand = [&](uint64_t q, int ntiles_q, uint32_t(*pk)[64 * WORDS], unsigned long long out) {
+#pragma unroll 1
+        for (int k = 0; k < ntiles_q; k++) {
+            uint32_t b[WORDS];
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int j = 0; j < WORDS; j++) {
+                b[j] = pk[k][lane * WORDS + j];
+                cnt += __builtin_popcount(b[j]);
+            }
+            if (__ballot(cnt != 0) == 0) continue; // nothing in this tile
+            const uint32_t incl = wave_inclusive_scan(cnt);
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            const uint64_t row0 = a.first_row + (q * K + k) * G::TILE_VALUES;
+            if (total <= 64) {
+                // one loop over the lane's whole run (lowest set bit of the first non-empty word): the wave iterates
+                // max-hits-per-lane times (1-2 for a selective predicate), not once per word and hit
+                uint64_t *dst = a.rowids + out;
+                uint32_t o = incl - cnt;
+                const uint32_t room = out >= a.capacity ? 0u : (a.capacity - out > 64 ? 64u : (uint32_t)(a.capacity - out));
+                const uint64_t r0 = row0 + lane * VPL;
+                uint32_t left = cnt;
+                while (left) {
+                    uint32_t w, jb;
+                    if constexpr (WORDS == 4) {
+                        w = b[0] ? b[0] : (b[1] ? b[1] : (b[2] ? b[2] : b[3]));
+                        jb = b[0] ? 0u : (b[1] ? 32u : (b[2] ? 64u : 96u));
+                    } else {
+                        w = b[0] ? b[0] : b[1];
+                        jb = b[0] ? 0u : 32u;
+                    }
+                    const uint32_t i = (uint32_t)__builtin_ctz(w);
+                    if (o < room) dst[o] = r0 + jb + i;
+                    o++;
+                    left--;
+                    const uint32_t cleared = w & (w - 1);
+                    if constexpr (WORDS == 4) {
+                        if (jb == 0) b[0] = cleared; else if (jb == 32) b[1] = cleared; else if (jb == 64) b[2] = cleared; else b[3] = cleared;
+                    } else {
+                        if (jb == 0) b[0] = cleared; else b[1] = cleared;
+                    }
+                }
+                out += total;
+                continue;
+            }
+            const uint32_t first_half = __builtin_amdgcn_readlane(incl, 31); // ids of lanes 0..31
+            // the stage holds the ids of half a tile: one pass when they fit, else lanes 0..31, then lanes 32..63
+            const int npass = total <= (uint32_t)HALF ? 1 : 2;
+#pragma unroll 1
+            for (int h = 0; h < npass; h++) {
+                const uint32_t base = h ? first_half : 0u;
+                const uint32_t count = npass == 1 ? total : (h ? total - first_half : first_half);
+                if (count == 0) continue;
+                if (npass == 1 || (lane >> 5) == h) {
+                    uint32_t p = incl - cnt - base;
+#pragma unroll
+                    for (int j = 0; j < WORDS; j++) {
+                        uint32_t w = b[j];
+                        const uint32_t off0 = lane * VPL + 32 * j;
+                        while (w) {
+                            const int i = __builtin_ctz(w);
+                            w &= w - 1;
+                            st[p++] = (uint16_t)(off0 + i);
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's stage writes are done (LDS is in order per wave)
+                for (uint32_t i = lane; i < count; i += 64) {
+                    const uint64_t o = out + base + i;
+                    if (o < a.capacity) a.rowids[o] = row0 + st[i];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // stage reads done before it is overwritten
+            }
+            out += total;
+        }
+    };
+
+    auto finish = [&](uint64_t q, unsigned long long q_hits, int ntiles_q, uint32_t(*pk)[64 * WORDS]) {
+        const unsigned long long before = (a.flags & 4u) ? 0ull : resolve(q, q_hits); // (flags: tuning aids, ablations)
+        if (q_hits && !gave_up && !(a.flags & 2u)) expand(q, ntiles_q, pk, before);
+        if (q == nchunks - 1 && lane == 0) a.hits[0] = gave_up ? ~0ull : before + q_hits; // the column's hit count
+    };
+
+    // Software pipeline over the wave's chunks: chunk g is resolved and expanded AFTER chunk g+1 has been decoded.  The
+    // persistent waves run in lock step, so right after its own decode a wave would find none of the ~1000 chunks in
+    // front of it finished and wait for the slowest of them -- a grid-wide barrier per generation (measured: 0.51 ms
+    // against 0.27 for the unfused chain).  One generation later their aggregates have long been published and the
+    // generation before that knows its inclusive prefixes: the look-back is one or two polls and never waits.
+    bool pend = false;
+    uint64_t pend_chunk = 0;
+    unsigned long long pend_hits = 0;
+    int pend_ntiles = 0;
+    int buf = 0;
+    while (chunk < nchunks) {
+        const uint64_t tfirst = chunk * K;
+        uint32_t(*const park)[64 * WORDS] = parked[wave][buf];
+        uint32_t lane_hits = 0;
+        int ntiles_here = 0; // tiles of this chunk inside the column
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            const uint64_t tile = tfirst + k;
+            if (tile < tc.ntiles) { // wave-uniform
+                ntiles_here = k + 1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                uint32_t w[G::LANE_DWORDS];
+                read_lane_data<C, VPL>(lds_wave, lane, w);
+                uint32_t mcur[WORDS];
+                const bool full = tile < tc.nfull;
+                if (mask && full) {
+#pragma unroll
+                    for (int j = 0; j < WORDS; j++) mcur[j] = ((const uint32_t *)(mlds_wave + lane * (WORDS * 4)))[j];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const uint64_t next = (k + 1 < K && tile + 1 < tc.ntiles) ? tile + 1 : (chunk + stride) * K;
+                if (next < tc.ntiles && (k + 1 < K || chunk + stride < nchunks)) issue_tile(next);
+
+                uint32_t r1[1][WORDS];
+                if constexpr (LK > 0) {
+                    decode_words_narrow<C, VPL, LK, 0, G::LANE_DWORDS>(w, r1, nlut);
+                } else {
+                    const uint32_t key8[kMaxKeysPerPass] = {key[0], key[1], 0, 0, 0, 0, 0, 0};
+                    decode_words<C, VPL, 0, 1, MODE, G::LANE_DWORDS>(w, r1, key8);
+                }
+#pragma unroll
+                for (int j = 0; j < WORDS; j++) r1[0][j] ^= inv;
+                if (full) {
+                    if (mask) {
+#pragma unroll
+                        for (int j = 0; j < WORDS; j++) r1[0][j] = combine(r1[0][j], mcur[j]);
+                    }
+                } else {
+                    const int64_t left = (int64_t)(tc.n - tile * G::TILE_VALUES) - (int64_t)lane * VPL;
+                    const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
+                    if (mask) { // ragged tile: read only the bytes the mask is guaranteed to hold (ceil(n/8))
+                        const uint8_t *mp = mask + tile * G::BITMAP_BYTES + lane * (WORDS * 4);
+                        const int nbytes = (valid + 7) / 8;
+#pragma unroll
+                        for (int j = 0; j < WORDS; j++) {
+                            uint32_t m = 0;
+#pragma unroll
+                            for (int b = 0; b < 4; b++)
+                                if (4 * j + b < nbytes) m |= (uint32_t)mp[4 * j + b] << (8 * b);
+                            r1[0][j] = combine(r1[0][j], m);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < WORDS; j++) r1[0][j] &= tail_mask(valid, j);
+                }
+#pragma unroll
+                for (int j = 0; j < WORDS; j++) {
+                    park[k][lane * WORDS + j] = r1[0][j];
+                    lane_hits += __builtin_popcount(r1[0][j]);
+                }
+            }
+        }
+        // the chunk's hits, published as its aggregate (chunk 0: as the first inclusive prefix)
+        const unsigned long long chunk_hits = wave_sum(lane_hits);
+        if (lane == 0)
+            __hip_atomic_store(state + chunk, ((chunk == 0 ? 2ull : 1ull) << 62) | chunk_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pend) finish(pend_chunk, pend_hits, pend_ntiles, parked[wave][buf ^ 1]);
+        pend = true;
+        pend_chunk = chunk;
+        pend_hits = chunk_hits;
+        pend_ntiles = ntiles_here;
+        buf ^= 1;
+        chunk += stride;
+    }
+    if (pend) finish(pend_chunk, pend_hits, pend_ntiles, parked[wave][buf ^ 1]);
+    if (gave_up && lane == 0) a.hits[0] = ~0ull;
+}
+
+} // namespace mi355

@@ -359,6 +359,22 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+// inclusive prefix sum over the 64 lanes with DPP moves (seven VALU operations; a __shfl_up ladder is six dependent
+// ds_bpermute round trips through the LDS crossbar): three row_shr of the input give every lane the sum of its group of
+// four, row_shr:4 / row_shr:8 (bank-masked) finish the 16-lane rows, row_bcast:15 / row_bcast:31 carry the row totals on.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    uint32_t r = x;
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); // row_shr:1
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); // row_shr:2
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false); // row_shr:3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xe, false); // row_shr:4, banks 1-3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xc, false); // row_shr:8, banks 2-3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1, 3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2, 3
+    return r;
+}
+
 // mask for bitmap word J of a lane that owns `valid` (0..VPL) in-range values
 __device__ __forceinline__ uint32_t tail_mask(int valid, int J)
 {

@@ -230,6 +230,16 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
             hipLaunchKernelGGL((in_kernel<C, 2, VPL>), dim3(grid_for(ntiles, want, r.num_cus)), dim3(kBlockThreads), 0, r.stream, r.scan);
         break;
     }
+    case kOpSelect: {
+        // predicate -> row ids: one block per CU (LDS: tiles + mask image + 16 KiB id stage per wave), every wave on a
+        // chunk of select_tiles(C) tiles; the grid must be fully resident (the look-back waits for running waves)
+        constexpr int VPL = scan_vpl(C, kModeRange);
+        using G = ScanGeom<C, VPL>;
+        const uint64_t ntiles = (r.scan.n + G::TILE_VALUES - 1) / G::TILE_VALUES;
+        const uint64_t nchunks = (ntiles + select_tiles(C) - 1) / select_tiles(C);
+        hipLaunchKernelGGL((select_kernel<C, kModeRange, VPL>), dim3(grid_for(nchunks, 1, r.num_cus)), dim3(kBlockThreads), 0, r.stream, r.scan);
+        break;
+    }
     case kOpDecompress: {
         static const int bpc = blocks_per_cu(decompress_kernel<C, 18>);
         const uint64_t ntiles = (r.decomp.n + DecompGeom<C>::TILE_VALUES - 1) / DecompGeom<C>::TILE_VALUES;

@@ -190,6 +190,17 @@ class ScanEngine:
                                            None if count_only else bitmap.data_ptr(), hits.data_ptr()))
         return (None if count_only else bitmap), hits
 
+    def scan_select(self, op: str, a: int, col: PackedColumn, capacity: int, b: int = 0, mask: Optional[torch.Tensor] = None,
+                    mask_op: str = "and", first_row: int = 0):
+        """predicate (optionally combined with an earlier bitmap) -> (int64 ascending row ids [capacity], count int64[1])
+        in one launch, no bitmap in HBM; ids beyond `capacity` are dropped, count is the total."""
+        rowids = torch.empty(max(capacity, 1), dtype=torch.int64, device=self._dev)
+        count = torch.empty(1, dtype=torch.int64, device=self._dev)
+        check(lib().mi355_scan_select_dev(self._ctx, col.data.data_ptr(), col.n, col.c, self._CMP[op], int(a), int(b),
+                                          self._BOP[mask_op], mask.data_ptr() if mask is not None else None, first_row,
+                                          rowids.data_ptr(), capacity, count.data_ptr()))
+        return rowids, count
+
     def scan_in(self, keys: Sequence[int], col: PackedColumn, negate: bool = False,
                 and_mask: Optional[torch.Tensor] = None, bitmap: Optional[torch.Tensor] = None,
                 hits: Optional[torch.Tensor] = None):

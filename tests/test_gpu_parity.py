@@ -667,6 +667,71 @@ def test_one_tile_per_burst_option_agrees(O, eng, c):
     assert np.array_equal(r4.cpu().numpy(), orb) and np.array_equal(r1.cpu().numpy(), orb) and int(hr4.item()) == orh == int(hr1.item())
 
 
+@pytest.mark.parametrize("c", [1, 4, 5, 7, 9, 13, 14, 16, 17, 21, 32])
+@pytest.mark.parametrize("n", [1, 77, 8192, 8192 * 16 + 5, 8192 * 16 * 5 + 4097, 1_000_003])
+def test_scan_select_matches_numpy(O, eng, c, n):
+    """mi355_scan_select_dev: predicate -> ascending row ids in one launch (no bitmap in HBM), against numpy: every
+    width class, one tile / one chunk / several chunks with a ragged tail, dense and sparse predicates, a fused mask,
+    a row offset, and a capacity smaller than the result"""
+    vals, col = make_column(O, eng, n, c, 9500 + c + n)
+    v = vals.astype(np.int64)
+    vmax = (1 << c) - 1
+    a = int(vals[n // 2])
+    for op, x, y, expect in (("==", a, 0, v == a), ("<=", vmax // 2, 0, v <= vmax // 2), ("!=", a, 0, v != a),
+                             ("between", 5, 2, np.zeros(n, bool))):
+        ids, cnt = eng.scan_select(op, x, col, capacity=n, b=y, first_row=10_000_000_000)
+        want = np.nonzero(expect)[0].astype(np.int64) + 10_000_000_000
+        k = int(cnt.item())
+        assert k == want.shape[0], (op, c, n)
+        assert np.array_equal(ids[:k].cpu().numpy(), want), (op, c, n)
+    mask, _ = eng.scan_where(">=", vmax // 4, col)
+    first = v >= vmax // 4
+    for mop, expect in (("and", (v <= a) & first), ("or", (v <= a) | first), ("andnot", first & ~(v <= a))):
+        ids, cnt = eng.scan_select("<=", a, col, capacity=n, mask=mask, mask_op=mop)
+        want = np.nonzero(expect)[0].astype(np.int64)
+        k = int(cnt.item())
+        assert k == want.shape[0] and np.array_equal(ids[:k].cpu().numpy(), want), (mop, c, n)
+    # capacity smaller than the result: the count is still the total, ids beyond the capacity are not written
+    import torch
+
+    expect = np.nonzero(v <= vmax // 2)[0].astype(np.int64)
+    cap = max(1, expect.shape[0] // 3)
+    ids, cnt = eng.scan_select("<=", vmax // 2, col, capacity=cap)
+    assert int(cnt.item()) == expect.shape[0]
+    assert np.array_equal(ids[: min(cap, expect.shape[0])].cpu().numpy(), expect[:cap])
+    torch.cuda.synchronize()
+
+
+def test_scan_select_1e9_chain(O, eng):
+    """1e9 x 9 bit: the fused select against the chain scan -> bitmap -> row ids (7630 chunks: the look-back crosses
+    many generations of the persistent grid), sparse (1/512) and dense (1/2) predicates, repeated"""
+    import torch
+
+    n, c = 1_000_000_000, 9
+    col = eng.generate("splitmix", n, c, 42)
+    key = int(O.gen_values("splitmix", 1, c, 42, first=12345)[0])
+    for rep in range(3):
+        bm, hits = eng.scan(key, col)
+        h = int(hits.item())
+        ids_ref, cnt_ref = eng.bitmap_to_rowids(bm, n, capacity=h)
+        ids, cnt = eng.scan_select("==", key, col, capacity=h)
+        assert int(cnt.item()) == h == int(cnt_ref.item())
+        assert torch.equal(ids[:h], ids_ref[:h])
+    del ids, ids_ref
+    bm, hits = eng.scan_where("<", 256, col)
+    h = int(hits.item())
+    ids_ref, cnt_ref = eng.bitmap_to_rowids(bm, n, capacity=h)
+    ids, cnt = eng.scan_select("<", 256, col, capacity=h)
+    assert int(cnt.item()) == h and torch.equal(ids[:h], ids_ref[:h])
+    # conjunction over "two columns": second predicate fused with the first one's bitmap, straight to row ids
+    ids2, cnt2 = eng.scan_select(">=", 200, col, capacity=h, mask=bm, mask_op="and")
+    dec = eng.decompress(col)
+    want = torch.nonzero((dec >= 200) & (dec < 256)).flatten()
+    assert int(cnt2.item()) == want.numel() and torch.equal(ids2[: want.numel()], want)
+    del dec, ids, ids_ref, ids2, col
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 127, 128, 1000, 16384, 16385, 100_003, 1_000_003])
 def test_bitmap_consumers(O, eng, n):
     import torch

@@ -61,15 +61,38 @@ def main():
         report(f"scan_in P={P}", timed(lambda: eng.scan_in(keys, col, bitmap=out, hits=h1)), pk + nb)
     report("bitmap_combine AND (+popcount)", timed(lambda: eng.bitmap_combine("and", bm_a, bm_b, n, out=out)), 3 * nb)
     report("bitmap_count", timed(lambda: eng.bitmap_count(bm_a, n)), nb)
-    for name, bm in (("1/512", eng.scan(key, col)[0]), ("1/2", bm_a)):
-        cnt = int(eng.bitmap_count(bm, n).item())
+    # fused consumers: what leaves out the bitmap round trip through HBM
+    report("scan == (bitmap + count)", timed(lambda: eng.scan(key, col, bitmap=out, hits=h1)), pk + nb)
+    report("scan_combine == count only (no bitmap)", timed(lambda: eng.scan_combine("==", key, col, hits=h1, count_only=True)), pk,
+           f"saves {nb / 1e6:.0f} MB of bitmap writes")
+    report("scan_combine < OR mask (fused disjunction)",
+           timed(lambda: eng.scan_combine("<", (1 << c) // 4, col, mask=bm_b, mask_op="or", bitmap=out, hits=h1)), pk + 2 * nb)
+    report("scan_combine < AND mask, count only", timed(lambda: eng.scan_combine("<", (1 << c) // 4, col, mask=bm_b, hits=h1, count_only=True)),
+           pk + nb)
+    for name, op, x in (("1/512", "==", key), ("1/2", "<", (1 << c) // 2)):
+        bm, hh = eng.scan_where(op, x, col)
+        cnt = int(hh.item())
         ids = None
 
-        def f():
+        def chain():
+            nonlocal ids
+            b2, _ = eng.scan_where(op, x, col, bitmap=out, hits=h1)
+            ids = eng.bitmap_to_rowids(b2, n, capacity=cnt)
+
+        def rowids_only():
             nonlocal ids
             ids = eng.bitmap_to_rowids(bm, n, capacity=cnt)
 
-        report(f"bitmap_to_rowids selectivity {name}", timed(f, 5), nb + 8 * cnt, f"{cnt} ids")
+        def fused():
+            nonlocal ids
+            ids = eng.scan_select(op, x, col, capacity=cnt)
+
+        report(f"bitmap_to_rowids selectivity {name}", timed(rowids_only, 5), nb + 8 * cnt, f"{cnt} ids")
+        t_chain = timed(chain, 5)
+        report(f"scan -> bitmap -> row ids, selectivity {name}", t_chain, pk + nb + 2 * nb + 8 * cnt, "4 launches; bitmap written once, read twice")
+        t_fused = timed(fused, 5)
+        report(f"scan_select (fused), selectivity {name}", t_fused, pk + 8 * cnt,
+               f"1 launch, no bitmap in HBM: {3 * nb / 1e6:.0f} MB less traffic, {t_chain / t_fused:.2f}x the chain's speed")
         del ids
         torch.cuda.empty_cache()
 
