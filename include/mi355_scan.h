@@ -191,6 +191,15 @@ MI355_API int mi355_scan_combine_dev(mi355_ctx *ctx, const void *packed_dev, uin
 MI355_API int mi355_scan_in_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const int32_t *keys_host, unsigned P,
                                 int negate, const void *and_mask_dev, void *bitmap_dev, uint64_t *hits_dev);
 
+/* Predicates over TWO columns of n rows each in one call:
+ *   bitmap[i] = COMBINE(p2(v2_i), p1(v1_i))    combine_op: MI355_BITMAP_AND p1 & p2, _OR p1 | p2, _XOR, _ANDNOT p1 & ~p2
+ * Columns of the same width run as ONE launch (both tiles in LDS, both decoded in registers: the first predicate's
+ * bitmap never exists in memory); different widths run as two launches with the combination fused into the second.
+ * bitmap_dev == NULL: count only. */
+MI355_API int mi355_scan2_dev(mi355_ctx *ctx, const void *packed1_dev, unsigned c1, int op1, int64_t a1, int64_t b1,
+                              const void *packed2_dev, unsigned c2, int op2, int64_t a2, int64_t b2, uint64_t n, int combine_op,
+                              void *bitmap_dev, uint64_t *hits_dev);
+
 /* Fused scan + selection vector: rowids_dev receives first_row + i, ascending, for every row i with
  *   mask_dev ? COMBINE(p[i], mask[i]) : p[i]        (p, mask_op as in mi355_scan_combine_dev)
  * (at most `capacity` ids are written), count_dev the number of such rows -- ONE launch, and no bitmap ever goes to HBM

@@ -50,6 +50,8 @@ SYMBOLS = [
     ("mi355_shared_scan_eq_dev", _int, [_vp, _vp, _u64, C.c_uint, _vp, C.c_uint, _int, _vp, _u64, _vp]),
     ("mi355_scan_where_dev", _int, [_vp, _vp, _u64, C.c_uint, _int, C.c_int64, C.c_int64, _vp, _vp, _vp]),
     ("mi355_scan_combine_dev", _int, [_vp, _vp, _u64, C.c_uint, _int, C.c_int64, C.c_int64, _int, _vp, _vp, _vp]),
+    ("mi355_scan2_dev", _int, [_vp, _vp, C.c_uint, _int, C.c_int64, C.c_int64, _vp, C.c_uint, _int, C.c_int64, C.c_int64, _u64, _int,
+                         _vp, _vp]),
     ("mi355_scan_select_dev", _int, [_vp, _vp, _u64, C.c_uint, _int, C.c_int64, C.c_int64, _int, _vp, _u64, _vp, _u64, _vp]),
     ("mi355_scan_in_dev", _int, [_vp, _vp, _u64, C.c_uint, _vp, C.c_uint, _int, _vp, _vp, _vp]),
     ("mi355_bitmap_combine_dev", _int, [_vp, _int, _vp, _vp, _vp, _u64, _vp]),

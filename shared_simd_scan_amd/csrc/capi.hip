@@ -686,6 +686,51 @@ int mi355_scan_select_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, un
     return launch(ctx, r);
 }
 
+int mi355_scan2_dev(mi355_ctx *ctx, const void *packed1_dev, unsigned c1, int op1, int64_t a1, int64_t b1, const void *packed2_dev,
+                    unsigned c2, int op2, int64_t a2, int64_t b2, uint64_t n, int combine_op, void *bitmap_dev, uint64_t *hits_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    CtxLock lk(ctx->mu);
+    if ((rc = check_width(c1)) || (rc = check_width(c2))) return rc;
+    if (op1 < MI355_CMP_EQ || op1 > MI355_CMP_NOT_BETWEEN || op2 < MI355_CMP_EQ || op2 > MI355_CMP_NOT_BETWEEN)
+        return fail(MI355_E_INVALID, "unknown comparison");
+    if (combine_op < MI355_BITMAP_AND || combine_op > MI355_BITMAP_ANDNOT) return fail(MI355_E_INVALID, "unknown combine op %d", combine_op);
+    if (!bitmap_dev && !hits_dev) return fail(MI355_E_INVALID, "bitmap_dev and hits_dev are both null: nothing to compute");
+    if (n == 0) {
+        if (hits_dev) HIP_TRY(hipMemsetAsync(hits_dev, 0, sizeof(uint64_t), ctx->stream));
+        return MI355_OK;
+    }
+    if (!packed1_dev || !packed2_dev) return fail(MI355_E_INVALID, "null device pointer");
+    if (((uintptr_t)packed1_dev & 15) || ((uintptr_t)packed2_dev & 15) || ((uintptr_t)bitmap_dev & 15))
+        return fail(MI355_E_INVALID, "packed columns and bitmap_dev must be 16-byte aligned");
+    if (c1 != c2) {
+        // columns of different widths have different tile geometries: two launches, the first predicate's bitmap
+        // combined inside the second scan, in place (every wave reads the mask bytes of a tile before it stores them)
+        void *tmp = bitmap_dev;
+        if (!tmp && (rc = pool_get(ctx, mi355_ctx::kPoolAux, bitmap_bytes(n) + 16, &tmp))) return rc;
+        if ((rc = mi355_scan_combine_dev(ctx, packed1_dev, n, c1, op1, a1, b1, MI355_BITMAP_AND, nullptr, tmp, nullptr))) return rc;
+        return mi355_scan_combine_dev(ctx, packed2_dev, n, c2, op2, a2, b2, combine_op, tmp, bitmap_dev, hits_dev);
+    }
+    LaunchReq r{};
+    r.op = kOpScan2;
+    r.c = c1;
+    r.scan.packed = (const uint8_t *)packed1_dev;
+    r.scan.packed2 = (const uint8_t *)packed2_dev;
+    r.scan.n = n;
+    r.scan.out = (uint8_t *)bitmap_dev;
+    r.scan.hits = (unsigned long long *)hits_dev;
+    r.scan.nkeys = 1;
+    r.scan.mask_op = (uint32_t)combine_op;
+    ScanArgs second{};
+    fill_predicate(second, c2, op2, a2, b2);
+    fill_predicate(r.scan, c1, op1, a1, b1);
+    r.scan.key2[0] = second.key[0];
+    r.scan.key2[1] = second.key[1];
+    r.scan.invert2 = second.invert;
+    return launch(ctx, r);
+}
+
 int mi355_scan_where_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, int op, int64_t a, int64_t b,
                          const void *and_mask_dev, void *bitmap_dev, uint64_t *hits_dev)
 {

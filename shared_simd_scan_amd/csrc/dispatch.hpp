@@ -8,7 +8,7 @@
 
 namespace mi355 {
 
-enum Op { kOpScanEq = 0, kOpScanRange = 1, kOpSharedScan = 2, kOpDecompress = 3, kOpScanIn = 4, kOpSelect = 5 };
+enum Op { kOpScanEq = 0, kOpScanRange = 1, kOpSharedScan = 2, kOpDecompress = 3, kOpScanIn = 4, kOpSelect = 5, kOpScan2 = 6 };
 
 struct LaunchReq {
     int op;

@@ -444,6 +444,73 @@ __global__ __launch_bounds__(kBlockThreads, (burst_occ<C, VPL, K>())) void scan_
     hits_finalize(a, 1, lane);
 }
 
+// ---- two columns, one launch: bitmap = COMBINE(p1(column 1), p2(column 2)) ------------------------------------------
+// The conjunction / disjunction of predicates over two columns of the same width without the first predicate's bitmap
+// ever going to HBM (the intent of src/simd_scan.hpp:76-84).  Per wave tile both columns' tiles are in
+// flight together (two LDS buffers per wave), both are decoded in registers, the result words are combined and leave
+// as in scan_burst_kernel with K = 1 (stores deferred one tile; out == nullptr: count only).  Both predicates are
+// inclusive ranges with a negation word (every comparison of mi355_scan_where_dev is one).
+template <int C, int AUX_, int VPL>
+__global__ __launch_bounds__(kBlockThreads, (burst_occ<C, VPL, 1>() > 1 ? burst_occ<C, VPL, 1>() / 2 : 1)) void scan2_kernel(ScanArgs a)
+{
+    using G = ScanGeom<C, VPL>;
+    constexpr int WORDS = G::WORDS;
+    constexpr int AUX = AUX_ & 15;
+    constexpr int NTS = (AUX_ & 32) ? 2 : ((AUX_ & 16) ? 1 : 0);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][2][G::LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds1 = lds[wave][0], *lds2 = lds[wave][1];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t k1[kMaxKeysPerPass] = {a.key[0], a.key[1], 0, 0, 0, 0, 0, 0};
+    const uint32_t k2[kMaxKeysPerPass] = {a.key2[0], a.key2[1], 0, 0, 0, 0, 0, 0};
+    const uint32_t inv1 = a.invert, inv2 = a.invert2, mop = a.mask_op;
+    auto combine = [mop](uint32_t p2, uint32_t p1) -> uint32_t { // (as the mask forms: p1 plays the earlier bitmap)
+        return mop == 0 ? (p2 & p1) : mop == 1 ? (p2 | p1) : mop == 2 ? (p2 ^ p1) : (p1 & ~p2);
+    };
+    uint32_t hits = 0;
+    uint8_t *const out_lane = a.out + lane * (WORDS * 4);
+    const bool store = a.out != nullptr;
+    uint32_t res[WORDS];
+    uint64_t prev = ~0ull;
+
+    auto issue = [&](uint64_t t) {
+        tc.template issue<AUX>(a.packed, t, lds1, lane);
+        tc.template issue<AUX>(a.packed2, t, lds2, lane);
+    };
+    if (tile < tc.ntiles) issue(tile);
+    while (tile < tc.ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t w1[G::LANE_DWORDS], w2[G::LANE_DWORDS];
+        read_lane_data<C, VPL>(lds1, lane, w1);
+        read_lane_data<C, VPL>(lds2, lane, w2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (prev != ~0ull && store) store_words<WORDS, NTS>(out_lane + prev * G::BITMAP_BYTES, res);
+        const uint64_t next = tile + stride;
+        if (next < tc.ntiles) issue(next);
+        uint32_t r1[1][WORDS], r2[1][WORDS];
+        decode_words<C, VPL, 0, 1, kModeRange, G::LANE_DWORDS>(w1, r1, k1);
+        decode_words<C, VPL, 0, 1, kModeRange, G::LANE_DWORDS>(w2, r2, k2);
+#pragma unroll
+        for (int j = 0; j < WORDS; j++) res[j] = combine(r2[0][j] ^ inv2, r1[0][j] ^ inv1);
+        if (tile < tc.nfull) {
+#pragma unroll
+            for (int j = 0; j < WORDS; j++) hits += __builtin_popcount(res[j]);
+            prev = tile;
+        } else {
+            hits += tc.finish_tail(tile, res, out_lane + tile * G::BITMAP_BYTES, 1, lane, store);
+            prev = ~0ull;
+        }
+        tile = next;
+    }
+    if (prev != ~0ull && store) store_words<WORDS, NTS>(out_lane + prev * G::BITMAP_BYTES, res);
+    if (a.hits) hits_add(a, 0, wave_sum(hits), lane);
+    hits_finalize(a, 1, lane);
+}
+
 // 4x4 byte transpose: c[j] byte i = r[i] byte j   (v_perm_b32: selector 0-3 = bytes of the 2nd operand, 4-7 = 1st)
 __device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&r)[4], uint32_t (&c)[4])
 {

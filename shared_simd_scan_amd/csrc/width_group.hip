@@ -240,6 +240,20 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         hipLaunchKernelGGL((select_kernel<C, kModeRange, VPL>), dim3(grid_for(nchunks, 1, r.num_cus)), dim3(kBlockThreads), 0, r.stream, r.scan);
         break;
     }
+    case kOpScan2: {
+        // two columns of this width in one launch: twice the DMA per tile, so half the blocks per CU of the plain scan
+        constexpr int VPL = scan_vpl(C, kModeRange);
+        using G = ScanGeom<C, VPL>;
+        static const int bpc = blocks_per_cu(scan2_kernel<C, 34, VPL>);
+        const uint64_t ntiles = (r.scan.n + G::TILE_VALUES - 1) / G::TILE_VALUES;
+        const dim3 grid(grid_for(ntiles, scan_bpc(bpc, 2 * G::TILE_BYTES, r), r.num_cus));
+        const int policy = r.scan_nt_stores < 0 ? (r.scan.n / 8 > (768ull << 20) ? 1 : 2) : r.scan_nt_stores;
+        if (policy == 1)
+            hipLaunchKernelGGL((scan2_kernel<C, 18, VPL>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+        else
+            hipLaunchKernelGGL((scan2_kernel<C, 34, VPL>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
+        break;
+    }
     case kOpDecompress: {
         static const int bpc = blocks_per_cu(decompress_kernel<C, 18>);
         const uint64_t ntiles = (r.decomp.n + DecompGeom<C>::TILE_VALUES - 1) / DecompGeom<C>::TILE_VALUES;

@@ -190,6 +190,21 @@ class ScanEngine:
                                            None if count_only else bitmap.data_ptr(), hits.data_ptr()))
         return (None if count_only else bitmap), hits
 
+    def scan2(self, col1: PackedColumn, op1: str, a1: int, col2: PackedColumn, op2: str, a2: int, b1: int = 0, b2: int = 0,
+              combine: str = "and", bitmap: Optional[torch.Tensor] = None, hits: Optional[torch.Tensor] = None,
+              count_only: bool = False):
+        """predicates over two columns of the same row count, combined (and / or / xor / andnot = p1 & ~p2) in one call;
+        same-width columns run as a single launch"""
+        assert col1.n == col2.n
+        if bitmap is None and not count_only:
+            bitmap = self.alloc_bitmap(col1.n)
+        if hits is None:
+            hits = torch.empty(1, dtype=torch.int64, device=self._dev)
+        check(lib().mi355_scan2_dev(self._ctx, col1.data.data_ptr(), col1.c, self._CMP[op1], int(a1), int(b1), col2.data.data_ptr(),
+                                    col2.c, self._CMP[op2], int(a2), int(b2), col1.n, self._BOP[combine],
+                                    None if count_only else bitmap.data_ptr(), hits.data_ptr()))
+        return (None if count_only else bitmap), hits
+
     def scan_select(self, op: str, a: int, col: PackedColumn, capacity: int, b: int = 0, mask: Optional[torch.Tensor] = None,
                     mask_op: str = "and", first_row: int = 0):
         """predicate (optionally combined with an earlier bitmap) -> (int64 ascending row ids [capacity], count int64[1])

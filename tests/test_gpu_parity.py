@@ -732,6 +732,28 @@ def test_scan_select_1e9_chain(O, eng):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("c1,c2", [(9, 9), (1, 1), (5, 5), (16, 16), (21, 21), (32, 32), (9, 12), (17, 5)])
+@pytest.mark.parametrize("n", [8192 * 9 + 77, 1000, 4096 * 33 + 1])
+def test_two_column_predicates(O, eng, c1, c2, n):
+    """mi355_scan2_dev: predicates over two columns combined in one call (same width: one launch, no intermediate
+    bitmap; different widths: two launches, the combination fused into the second) against numpy"""
+    v1, col1 = make_column(O, eng, n, c1, 9700 + c1 + n)
+    v2, col2 = make_column(O, eng, n, c2, 9800 + c2 + n)
+    a1, a2 = int(v1[3]), int(v2[7])
+    p1 = v1.astype(np.int64) <= a1
+    p2 = v2.astype(np.int64) != a2
+    for comb, expect in (("and", p1 & p2), ("or", p1 | p2), ("xor", p1 ^ p2), ("andnot", p1 & ~p2)):
+        bm, hits = eng.scan2(col1, "<=", a1, col2, "!=", a2, combine=comb)
+        assert np.array_equal(bm.cpu().numpy(), np_bitmap(expect)), (comb, c1, c2, n)
+        assert int(hits.item()) == int(expect.sum())
+        none, hits = eng.scan2(col1, "<=", a1, col2, "!=", a2, combine=comb, count_only=True)
+        assert none is None and int(hits.item()) == int(expect.sum())
+    lo, hi = int(min(v2[1], v2[2])), int(max(v2[1], v2[2]))
+    bm, hits = eng.scan2(col1, "==", a1, col2, "between", lo, b2=hi, combine="or")
+    expect = (v1.astype(np.int64) == a1) | ((v2.astype(np.int64) >= lo) & (v2.astype(np.int64) <= hi))
+    assert np.array_equal(bm.cpu().numpy(), np_bitmap(expect)) and int(hits.item()) == int(expect.sum())
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 127, 128, 1000, 16384, 16385, 100_003, 1_000_003])
 def test_bitmap_consumers(O, eng, n):
     import torch

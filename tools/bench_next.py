@@ -69,6 +69,20 @@ def main():
            timed(lambda: eng.scan_combine("<", (1 << c) // 4, col, mask=bm_b, mask_op="or", bitmap=out, hits=h1)), pk + 2 * nb)
     report("scan_combine < AND mask, count only", timed(lambda: eng.scan_combine("<", (1 << c) // 4, col, mask=bm_b, hits=h1, count_only=True)),
            pk + nb)
+    # two columns: one launch against scan + fused-mask scan
+    col2 = eng.generate("splitmix", n, c, 4242)
+
+    def two_launches():
+        b1, _ = eng.scan_where("<", (1 << c) // 4, col, bitmap=out, hits=h1)
+        eng.scan_combine(">=", (1 << c) // 8, col2, mask=b1, mask_op="and", bitmap=out, hits=h1)
+
+    t2 = timed(two_launches)
+    report("col1 < a AND col2 >= b: scan + fused-mask scan", t2, 2 * pk + 3 * nb, "2 launches, 125 MB bitmap written + read in between")
+    t1 = timed(lambda: eng.scan2(col, "<", (1 << c) // 4, col2, ">=", (1 << c) // 8, combine="and", bitmap=out, hits=h1))
+    report("col1 < a AND col2 >= b: mi355_scan2_dev", t1, 2 * pk + nb, f"1 launch, no intermediate bitmap: {t2 / t1:.2f}x")
+    report("col1 < a AND col2 >= b: scan2, count only", timed(lambda: eng.scan2(col, "<", (1 << c) // 4, col2, ">=", (1 << c) // 8, hits=h1, count_only=True)), 2 * pk)
+    del col2
+    torch.cuda.empty_cache()
     for name, op, x in (("1/512", "==", key), ("1/2", "<", (1 << c) // 2)):
         bm, hh = eng.scan_where(op, x, col)
         cnt = int(hh.item())
