@@ -827,6 +827,24 @@ def test_interleaved_launches_keep_scratch_clean(O, eng):
         ids, cnt = eng.bitmap_to_rowids(bm, n, capacity=16)
         assert int(cnt.item()) == int(hr.item())
     torch.cuda.synchronize()
+    # a stream switch in the middle of queued work: the scratch belongs to the context, so mi355_ctx_set_stream orders the
+    # new stream behind what the old one still has to run (no host synchronisation in between)
+    original = eng.stream
+    side = torch.cuda.Stream()
+    try:
+        for rnd in range(4):
+            key = int(vals[50 + rnd])
+            _, h_a = eng.shared_scan(keys100, col)          # long-running launch on the current stream
+            eng.use_stream(side if rnd % 2 == 0 else original)
+            _, h_b = eng.scan(key, col)                     # same scratch, other stream
+            _, h_c = eng.shared_scan(keys8, col)
+            torch.cuda.synchronize()
+            assert np.array_equal(h_a.cpu().numpy().astype(np.uint64), exp100)
+            assert int(h_b.item()) == int((v == key).sum())
+            assert np.array_equal(h_c.cpu().numpy().astype(np.uint64), exp8)
+    finally:
+        eng.use_stream(original)
+    torch.cuda.synchronize()
 
 
 def test_two_contexts_two_streams(O):

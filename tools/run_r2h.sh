@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 2 evidence: rocprofv3 stats + PMC per workload, width sweep, P sweep, next-row bench, host path
+set -o pipefail
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r2h; mkdir -p $O
+for w in scan_eq scan_range shared_scan decompress; do
+  bash tools/profile.sh $w r02 > $O/profile_$w.log 2>&1; echo "profile $w rc=$?"
+done
+python tools/sweep.py --bits 1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32 --bpc 0 --reps 8 > $O/width_sweep.txt 2>&1; echo "width sweep rc=$?"
+python tools/sweep_p.py --burst 5 --reps 5 > $O/p_sweep.txt 2>&1; echo "p sweep rc=$?"
+python tools/bench_next.py > $O/bench_next.txt 2>&1; echo "bench_next rc=$?"
+python tools/pcie_rate.py > $O/pcie.txt 2>&1; echo "pcie rc=$?"
+python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+python bench.py --column random > $O/bench_random.json 2>> $O/bench.err; echo "bench random rc=$?"
