@@ -9,6 +9,9 @@
 // Differences a caller can observe:
 //   * the host-pointer path copies the packed column to the GPU and the result back on every call
 //     (drop-in convenience; use the *_dev entry points of mi355_scan.h to keep columns resident in HBM);
+//   * like the reference's functions (src/simd_scan_shared.cpp:25-32 calls scan_128 from an OpenMP loop) these may
+//     be called from any number of host threads at once: every call below passes ctx == NULL, which is the CALLING
+//     THREAD's default context (own scratch and device buffers); nothing is shared between threads;
 //   * failures of the device path (no GPU, HIP error) throw std::runtime_error -- the reference has no
 //     failure modes; there is no CPU fallback;
 //   * BITS_NEEDED may be defined before including this header (the reference hard-wires 9).
