@@ -44,6 +44,7 @@ def parse():
                     help="result stores of the scans: -1 engine default, 0 plain, 1 non-temporal, 2 write-through (tuning)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --rows per GPU; strong: --rows in total, row-range sharded at 8192-row boundaries")
+    ap.add_argument("--gather-timeout", type=float, default=180.0, help="N>1: seconds the exchange step may take before it is given up")
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads of the multi-core CPU leg (0 = every CPU this process may use: affinity mask / cgroup quota)")
@@ -239,7 +240,7 @@ def main():
         algo_bytes = n * c / 8 + n / 8
         kname = kernel_name("scan_range", c)
     elif args.workload == "shared_scan":
-        stride = (nb + 15) // 16 * 16
+        stride = (nb + 255) // 256 * 256  # per-predicate bitmaps start on whole 128-byte lines (mi355_bitmap_stride)
         bitmap = torch.empty((8, stride) if args.layout == "per_predicate" else (nb * 8,), dtype=torch.uint8, device="cuda")
         hits = torch.zeros(8, dtype=torch.int64, device="cuda")
         step = lambda: eng.shared_scan(keys8, col, layout=args.layout, out=bitmap, hits=hits)  # noqa: E731
@@ -294,60 +295,80 @@ def main():
         got = [int(x) for x in hits.tolist()]
         assert got == want, f"shared-scan hits {got} != {want}"
 
-    gather_ms, gather_error, pipelined_ms, gather_via = None, None, None, None
-    if world > 1 and not args.no_gather and args.workload in ("scan_eq", "scan_range"):
-        # final exchange step of the north star: per-shard bitmaps -> rank 0 over xGMI, through the C ABI's RCCL entry
-        # points (mi355_comm_create / mi355_gather_bitmaps_dev / mi355_allreduce_hits_dev); a gloo group (rehearsal on a
-        # box with fewer GPUs than ranks) uses the torch.distributed transport instead
-        from shared_simd_scan_amd.sharded import ShardedColumn, TorchExchange, make_exchange
+    xr = {"gather_ms": None, "gather_error": None, "pipelined_ms": None, "gather_via": None, "done": False}
 
-        if args.scaling == "strong":
-            sizes = [(b - a + 7) // 8 for a, b in shard_rows(args.rows, world)]
-        else:
-            sizes = [nb] * world
-        ex = None
-        try:
-            ex = make_exchange(eng, None)
-        except Exception as e:  # RCCL bootstrap through the C ABI failed: say so, fall back to torch's own group
-            gather_error = f"C-ABI RCCL exchange unavailable ({type(e).__name__}: {e}); torch.distributed used"
-            ex = TorchExchange(None)
-        gather_via = ex.name
-        try:
-            full = ex.gather(bitmap[:nb], sizes, dst=0, engine=eng)  # warm
-            total_hits = ex.sum_hits(hits, engine=eng)
-            sync_all()
-            g0 = time.perf_counter()
-            reps = 5
-            for _ in range(reps):
-                full = ex.gather(bitmap[:nb], sizes, dst=0, out=full, engine=eng)
-            sync_all()
-            gather_ms = (time.perf_counter() - g0) / reps * 1e3
-            gather_ms = reduce_max(gather_ms)
-            if expect_hits is not None and args.scaling == "weak":
-                want = sum(((r + 1) * n - 3 + 4) // 5 - (r * n - 3 + 4) // 5 for r in range(world))
-                assert int(total_hits.item()) == want, f"all-reduced hits {int(total_hits.item())} != {want}"
-            if rank == 0:  # the root's own slice must have arrived where the packed layout puts it
-                assert torch.equal(full[:nb], bitmap[:nb]), "gathered bitmap: the root's own slice differs"
-        except Exception as e:  # the scan figures above stand on their own; report the exchange step as failed
-            gather_error = f"{type(e).__name__}: {e}"
-        if args.pipelined_gather and args.workload == "scan_eq" and gather_ms is not None:
+    def exchange_phase():
+        """the exchange step, timed apart from the scan; runs in a helper thread so that a bootstrap or collective that
+        never returns (a mis-configured fabric) cannot take the already measured scan line down with it"""
+        torch.cuda.set_device(local_rank)
+        if world > 1 and not args.no_gather and args.workload in ("scan_eq", "scan_range"):
+            # final exchange step of the north star: per-shard bitmaps -> rank 0 over xGMI, through the C ABI's RCCL entry
+            # points (mi355_comm_create / mi355_gather_bitmaps_dev / mi355_allreduce_hits_dev); a gloo group (rehearsal on a
+            # box with fewer GPUs than ranks) uses the torch.distributed transport instead
+            from shared_simd_scan_amd.sharded import ShardedColumn, TorchExchange, make_exchange
+
+            if args.scaling == "strong":
+                sizes = [(b - a + 7) // 8 for a, b in shard_rows(args.rows, world)]
+            else:
+                sizes = [nb] * world
+            ex = None
             try:
-                sc = ShardedColumn(total_rows, c, engine=eng, exchange=ex)
-                if args.scaling == "weak":  # every rank owns exactly --rows rows
-                    sc.ranges = [(r * n, (r + 1) * n) for r in range(world)]
-                    sc.first, sc.last, sc.rows = first, first + n, n
-                sc.col = col
-                sc.scan_pipelined(key, dst=0, chunks=4)  # warm
+                ex = make_exchange(eng, None)
+            except Exception as e:  # RCCL bootstrap through the C ABI failed: say so, fall back to torch's own group
+                xr["gather_error"] = f"C-ABI RCCL exchange unavailable ({type(e).__name__}: {e}); torch.distributed used"
+                ex = TorchExchange(None)
+            xr["gather_via"] = ex.name
+            try:
+                full = ex.gather(bitmap[:nb], sizes, dst=0, engine=eng)  # warm
+                total_hits = ex.sum_hits(hits, engine=eng)
                 sync_all()
                 g0 = time.perf_counter()
-                for _ in range(5):
-                    full_p, hits_p = sc.scan_pipelined(key, dst=0, chunks=4)
+                reps = 5
+                for _ in range(reps):
+                    full = ex.gather(bitmap[:nb], sizes, dst=0, out=full, engine=eng)
                 sync_all()
-                pipelined_ms = reduce_max((time.perf_counter() - g0) / 5 * 1e3)
-                if rank == 0:
-                    assert torch.equal(full_p, full), "pipelined gather: bitmap differs from the plain gather"
-            except Exception as e:
-                gather_error = f"pipelined: {type(e).__name__}: {e}"
+                xr["gather_ms"] = reduce_max((time.perf_counter() - g0) / reps * 1e3)
+                if expect_hits is not None and args.scaling == "weak":
+                    want = sum(((r + 1) * n - 3 + 4) // 5 - (r * n - 3 + 4) // 5 for r in range(world))
+                    assert int(total_hits.item()) == want, f"all-reduced hits {int(total_hits.item())} != {want}"
+                if rank == 0:  # every slice must have arrived where the packed layout puts it
+                    assert torch.equal(full[:nb], bitmap[:nb]), "gathered bitmap: the root's own slice differs"
+                    if expect_hits is not None and args.scaling == "weak" and n % 40 == 0:
+                        # i % 5 column, shards of a multiple of 40 rows: every shard's bitmap is the same bytes
+                        for r in range(1, world):
+                            assert torch.equal(full[r * nb:(r + 1) * nb], bitmap[:nb]), f"gathered bitmap: slice of rank {r} differs"
+            except Exception as e:  # the scan figures above stand on their own; report the exchange step as failed
+                xr["gather_error"] = f"{type(e).__name__}: {e}"
+            if args.pipelined_gather and args.workload == "scan_eq" and xr["gather_ms"] is not None:
+                try:
+                    sc = ShardedColumn(total_rows, c, engine=eng, exchange=ex)
+                    if args.scaling == "weak":  # every rank owns exactly --rows rows
+                        sc.ranges = [(r * n, (r + 1) * n) for r in range(world)]
+                        sc.first, sc.last, sc.rows = first, first + n, n
+                    sc.col = col
+                    sc.scan_pipelined(key, dst=0, chunks=4)  # warm
+                    sync_all()
+                    g0 = time.perf_counter()
+                    for _ in range(5):
+                        full_p, hits_p = sc.scan_pipelined(key, dst=0, chunks=4)
+                    sync_all()
+                    xr["pipelined_ms"] = reduce_max((time.perf_counter() - g0) / 5 * 1e3)
+                    if rank == 0:
+                        assert torch.equal(full_p, full), "pipelined gather: bitmap differs from the plain gather"
+                except Exception as e:
+                    xr["gather_error"] = f"pipelined: {type(e).__name__}: {e}"
+
+        xr["done"] = True
+
+    import threading
+
+    th = threading.Thread(target=exchange_phase, daemon=True)
+    th.start()
+    th.join(args.gather_timeout)
+    timed_out = th.is_alive()
+    if timed_out:
+        xr["gather_error"] = f"exchange step did not finish within {args.gather_timeout} s (scan figures unaffected)"
+    gather_ms, gather_error, pipelined_ms, gather_via = xr["gather_ms"], xr["gather_error"], xr["pipelined_ms"], xr["gather_via"]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -387,6 +408,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "scan_eq":
             line["cpu_baseline"] = cpu_baseline(args, col, bitmap, key)
         print(json.dumps(line), flush=True)
+    if timed_out:
+        sys.stdout.flush()
+        os._exit(0)  # a rank stuck inside the exchange cannot be joined; the line above is complete without it
     if world > 1:
         dist.destroy_process_group()
 

@@ -136,7 +136,7 @@ static void bench_shared_scan(mi355_ctx *ctx, size_t data_size, size_t reps, int
     // optional 5th argument is "hits")
     std::vector<int32_t> keys(P);
     for (int i = 0; i < P; i++) keys[i] = i; // src/benchmark.cpp:205-209
-    const size_t nb = (n + 7) / 8, stride = (nb + 15) / 16 * 16;
+    const size_t nb = (n + 7) / 8, stride = mi355_bitmap_stride(n);
     void *packed, *out, *hits;
     CHECK(mi355_dev_alloc(ctx, mi355_compressed_buffer_size(c, n), &packed));
     CHECK(mi355_dev_alloc(ctx, stride * P + 64, &out));

@@ -97,6 +97,9 @@ MI355_API int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value);
 MI355_API size_t mi355_compressed_buffer_size(unsigned c, size_t n);
 MI355_API size_t mi355_decompression_output_buffer_size(size_t n);
 MI355_API size_t mi355_scan_output_buffer_size(size_t n);
+/* recommended distance in bytes between the per-predicate bitmaps of a shared scan over n rows: ceil(n/8) rounded up to
+ * 256, so that every bitmap starts on a whole 128-byte line (see mi355_shared_scan_eq_dev) */
+MI355_API size_t mi355_bitmap_stride(size_t n);
 
 /* ---- device memory helpers (hipMalloc / hipMemcpy / hipMemset on the context's device) ------- */
 MI355_API int mi355_dev_alloc(mi355_ctx *ctx, size_t bytes, void **dptr);
@@ -148,7 +151,9 @@ MI355_API int mi355_scan_range_dev(mi355_ctx *ctx, const void *packed_dev, uint6
  *   host, per-predicate: outputs[k] points at >= ceil(n/8) bytes for key k;
  *   host, linear:        output holds ceil(n/8)*P bytes, byte of 8-value group g and key k at g*P+k;
  *   _dev: out_dev is one 16-byte-aligned device buffer; per-predicate bitmaps start at out_dev + k*stride_bytes
- *         (stride_bytes a multiple of 16, >= ceil(n/8)); linear ignores stride_bytes.
+ *         (stride_bytes a multiple of 16, >= ceil(n/8); use mi355_bitmap_stride(n): bitmaps that start in the middle of
+ *         a 128-byte line make every wave store touch partial lines -- measured up to 2x slower at P >= 64, where the
+ *         result streams bound the kernel); linear ignores stride_bytes.
  * The reference's shared scans return no counts: pass hits = NULL for exactly its work (with counts the engine
  * may pick a different kernel; the bitmaps are the same).  "scan_nt_stores" also governs these result stores. */
 MI355_API int mi355_shared_scan_eq(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, const int32_t *keys,

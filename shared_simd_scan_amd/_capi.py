@@ -29,6 +29,7 @@ SYMBOLS = [
     ("mi355_compressed_buffer_size", _sz, [C.c_uint, _sz]),
     ("mi355_decompression_output_buffer_size", _sz, [_sz]),
     ("mi355_scan_output_buffer_size", _sz, [_sz]),
+    ("mi355_bitmap_stride", _sz, [_sz]),
     ("mi355_dev_alloc", _int, [_vp, _sz, C.POINTER(_vp)]),
     ("mi355_dev_free", _int, [_vp, _vp]),
     ("mi355_dev_upload", _int, [_vp, _vp, _vp, _sz]),

@@ -306,6 +306,7 @@ size_t mi355_compressed_buffer_size(unsigned c, size_t n)
 }
 size_t mi355_decompression_output_buffer_size(size_t n) { return n * 4 + 32; }
 size_t mi355_scan_output_buffer_size(size_t n) { return n / 8 + (n % 8 != 0) + 32; }
+size_t mi355_bitmap_stride(size_t n) { return (n / 8 + (n % 8 != 0) + 255) / 256 * 256; }
 
 /* ---- device memory ---- */
 int mi355_dev_alloc(mi355_ctx *ctx, size_t bytes, void **dptr)
@@ -948,7 +949,7 @@ static int shared_host(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsi
         return fail(MI355_E_INVALID, "null pointer");
     if ((rc = bind(ctx))) return rc;
     const size_t nb = bitmap_bytes(n);
-    const size_t stride = (nb + 15) / 16 * 16;
+    const size_t stride = mi355_bitmap_stride(n);
     void *dp = nullptr, *dout = nullptr;
     if ((rc = upload_packed(ctx, packed_host, n, c, &dp))) return rc;
     if ((rc = pool_get(ctx, mi355_ctx::kPoolOut, (layout == MI355_LAYOUT_PER_PREDICATE ? stride : nb) * P + 16, &dout))) return rc;

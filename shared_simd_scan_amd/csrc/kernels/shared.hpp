@@ -861,4 +861,140 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide_kernel(ScanArgs a)
     hits_finalize(a, P, lane);
 }
 
+// ---- shared scan, P > 8, per-predicate bitmaps: whole bitmap words at a time -------------------------------------
+// shared_wide_kernel transposes every 8-value group on its own (two 4x4 byte transposes, four 8x8 bit transposes inside
+// register pairs, then a byte gather per key): ~0.6 VALU operations per (value, key) result, most of them VOP3 (half
+// rate), and ~70 % of the kernel's time on MI355X.  Here the 32 lookups of a 32-value bitmap word are regrouped by eight
+// 4x4 byte transposes so that register R[b][i] holds key-byte b of values i, 8+i, 16+i, 24+i, and each key-byte takes
+// the register-wise 8x8 bit transpose of the one-pass kernel (transpose_bits_8regs: 72 VOP2 operations for 32 values x
+// 8 keys): afterwards R[b][q] IS the bitmap word of key 8b + q -- 0.34 operations per result, no gather.
+template <int C, int AUX_, int VPL>
+__global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
+{
+    using G = ScanGeom<C, VPL>;
+    using L = WideLutGeom<C>;
+    constexpr int WORDS = G::WORDS;
+    constexpr int AUX = AUX_ & 15;
+    constexpr int NTS = (AUX_ & 32) ? 2 : ((AUX_ & 16) ? 1 : 0); // result stores: 1 non-temporal, 2 write-through (sc1)
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+    __shared__ uint32_t s_hits[kMaxKeys]; // per-block hit counters (block_hits_add8)
+    uint32_t *const lut = (uint32_t *)mi355_dyn_lds; // ceil(P/32) * TABLE_BYTES dynamic bytes
+    for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxKeys; k += kBlockThreads) s_hits[k] = 0;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t P = a.nkeys;
+    const uint32_t npass32 = (P + 31) / 32;
+
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+
+    for (uint32_t i = threadIdx.x; i < npass32 * L::TABLE_DWORDS; i += kBlockThreads) lut[i] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) {
+        const uint32_t key = (uint32_t)a.keys_dev[k];
+        const bool in_range = C == 32 || (key >> (C & 31)) == 0;
+        if (in_range) {
+#pragma unroll
+            for (int d = 0; d < L::ND; d++) {
+                const uint32_t e = L::SINGLE ? key : L::digit(key, d);
+                __hip_atomic_fetch_or(lut + (k >> 5) * L::TABLE_DWORDS + d * L::ENTRIES + e, 1u << (k & 31), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+
+    uint32_t behind = 0; // stores issued after the DMA the next wait is for (wait_dma_behind_stores)
+    while (tile < tc.ntiles) {
+        wait_dma_behind_stores(behind);
+        uint32_t w[G::LANE_DWORDS];
+        read_lane_data<C, VPL>(lds_wave, lane, w);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint64_t next = tile + stride;
+        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        const bool full = tile < tc.nfull;
+        behind = (full && !(a.flags & 1u)) ? P : 0;
+        uint32_t xs[VPL];
+        extract_all<C, VPL, 0, G::LANE_DWORDS>(w, xs);
+        const int64_t left = (int64_t)(tc.n - tile * G::TILE_VALUES) - (int64_t)lane * VPL;
+        const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
+
+        // (flags bit 2, experiment: every wave starts its round-robin over the 32-key rounds at a different round, so the
+        // waves of the lock-stepped grid do not all write the same 32 output streams at the same time)
+        const uint32_t rot = (a.flags & 4u) ? (uint32_t)((blockIdx.x * kWavesPerBlock + wave) % npass32) : 0u;
+        for (uint32_t pi = 0; pi < npass32; pi++) {
+            const uint32_t p32 = pi + rot < npass32 ? pi + rot : pi + rot - npass32;
+            const uint32_t *table = lut + p32 * L::TABLE_DWORDS;
+            const uint32_t nb = ((P - p32 * 32) < 32 ? (P - p32 * 32) + 7 : 39) / 8; // key-bytes in use, 1..4
+            uint32_t outw[4][8][WORDS]; // [key-byte][key in byte][bitmap word of the lane]
+#pragma unroll
+            for (int j = 0; j < WORDS; j++) {
+                uint32_t R[4][8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    uint32_t r[4], c[4];
+#pragma unroll
+                    for (int Lg = 0; Lg < 4; Lg++) {
+                        const int v = 32 * j + 8 * Lg + i;
+                        uint32_t m = L::lookup(table, xs[v]);
+                        if (!full) m = v < valid ? m : 0u; // ragged tile: values >= n contribute nothing
+                        r[Lg] = m;
+                    }
+                    transpose4x4_bytes(r, c); // c[b] byte Lg = key-byte b of value 8 Lg + i
+#pragma unroll
+                    for (int b = 0; b < 4; b++) R[b][i] = c[b];
+                }
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    if ((uint32_t)b < nb) transpose_bits_8regs(R[b]);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) outw[b][q][j] = R[b][q];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t pass = p32 * 4 + b;
+                if (pass * 8 < P) {
+                    if (a.hits) {
+                        uint32_t cnt[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            cnt[q] = 0;
+#pragma unroll
+                            for (int j = 0; j < WORDS; j++) cnt[q] += __builtin_popcount(outw[b][q][j]);
+                        }
+                        block_hits_add8(s_hits, pass * 8, P, cnt, lane);
+                    }
+                    uint8_t *dst = a.out + (uint64_t)(pass * 8) * a.out_stride + tile * G::BITMAP_BYTES + lane * (WORDS * 4);
+                    if (full) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            if (pass * 8 + q < P) store_words<WORDS, NTS>(dst, outw[b][q]);
+                            dst += a.out_stride;
+                        }
+                    } else {
+                        const int nbytes = (valid + 7) / 8; // the bitmap is written byte-exact
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            if (pass * 8 + q < P) {
+#pragma unroll
+                                for (int bb = 0; bb < WORDS * 4; bb++)
+                                    if (bb < nbytes) dst[bb] = (uint8_t)(outw[b][q][bb >> 2] >> (8 * (bb & 3)));
+                            }
+                            dst += a.out_stride;
+                        }
+                    }
+                }
+            }
+        }
+        tile = next;
+    }
+    if (a.hits) block_hits_flush(a, s_hits, P);
+    hits_finalize(a, P, lane);
+}
+
 } // namespace mi355

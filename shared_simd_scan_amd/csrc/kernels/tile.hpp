@@ -352,13 +352,6 @@ __device__ __forceinline__ void read_lane_data(const uint8_t *lds_wave, int lane
     }
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // inclusive prefix sum over the 64 lanes with DPP moves (seven VALU operations; a __shfl_up ladder is six dependent
 // ds_bpermute round trips through the LDS crossbar): three row_shr of the input give every lane the sum of its group of
 // four, row_shr:4 / row_shr:8 (bank-masked) finish the 16-lane rows, row_bcast:15 / row_bcast:31 carry the row totals on.
@@ -373,6 +366,14 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
     r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1, 3
     r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2, 3
     return r;
+}
+
+// sum over the 64 lanes, the same value in every lane (wave-uniform): the DPP scan above, then lane 63's total
+// (a __shfl_xor butterfly is six dependent ds_bpermute round trips; the multi-pass shared scans reduce four packed
+// counters per eight keys and tile)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
 }
 
 // mask for bitmap word J of a lane that owns `valid` (0..VPL) in-range values

@@ -199,7 +199,14 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
             allow_dynamic_lds<shared_wide_kernel<C, 18, VPL, 0>>(max_dyn, r.device);
             const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : 2;
             const dim3 grid(grid_for(ntiles, want, r.num_cus));
-            if (linear)
+            if (!linear && !(r.scan.flags & 2u)) { // (flags bit 1: the per-group kernel, for A/B)
+                allow_dynamic_lds<shared_wide2_kernel<C, 2, VPL>>(max_dyn, r.device);
+                allow_dynamic_lds<shared_wide2_kernel<C, 18, VPL>>(max_dyn, r.device);
+                if (nt_stores)
+                    hipLaunchKernelGGL((shared_wide2_kernel<C, 18, VPL>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+                else
+                    hipLaunchKernelGGL((shared_wide2_kernel<C, 2, VPL>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+            } else if (linear)
                 hipLaunchKernelGGL((shared_wide_kernel<C, 2, VPL, 1>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
             else if (nt_stores)
                 hipLaunchKernelGGL((shared_wide_kernel<C, 18, VPL, 0>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);

@@ -356,6 +356,29 @@ def test_shared_scan_compare_chain_fallback(O, eng, L, c, P, layout, count):
         assert np.array_equal(hits.cpu().numpy(), np.array([int((v == k).sum()) for k in keys]))
 
 
+@pytest.mark.parametrize("P", [3, 8, 40, 64])
+def test_shared_scan_accepts_any_16_byte_stride(O, eng, L, P):
+    """per-predicate bitmaps may sit at any 16-byte-multiple stride >= ceil(n/8) (mi355_bitmap_stride, whole 128-byte
+    lines, is the fast choice the engine's own callers use): results are the same bytes"""
+    import torch
+
+    n, c = 8192 * 6 + 999, 9
+    vals, col = make_column(O, eng, n, c, 5400 + P)
+    keys = np.ascontiguousarray(vals[:P].astype(np.int32))
+    nb = (n + 7) // 8
+    assert L.mi355_bitmap_stride(n) % 256 == 0 and L.mi355_bitmap_stride(n) >= nb
+    oout, ohits = O.shared_scan_eq(col.data.cpu().numpy(), n, c, [int(k) for k in keys])
+    for stride in ((nb + 15) // 16 * 16, (nb + 15) // 16 * 16 + 48, L.mi355_bitmap_stride(n)):
+        out = torch.full((P * stride + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+        hits = torch.zeros(P, dtype=torch.int64, device="cuda")
+        ok(L, L.mi355_shared_scan_eq_dev(eng._ctx, col.data.data_ptr(), n, c, vp(keys), P, 0, out.data_ptr(), stride, hits.data_ptr()))
+        got = out.cpu().numpy()
+        for k in range(P):
+            assert np.array_equal(got[k * stride: k * stride + nb], oout[k]), (P, stride, k)
+            assert (got[k * stride + nb: (k + 1) * stride] == 0xEE).all()  # nothing written between the bitmaps
+        assert np.array_equal(hits.cpu().numpy().astype(np.uint64), ohits)
+
+
 def test_out_of_range_keys_never_match(O, eng):
     """SURVEY 8c hazard 5: keys 515, 1027, 65539, -1 on a 9-bit column -> no hits, zero bitmap."""
     import torch

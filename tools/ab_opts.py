@@ -41,7 +41,7 @@ for c in [int(x) for x in args.bits.split(",")]:
     key = 3
     if args.workload == "shared":
         keys = [(37 * k + 3) % (1 << c) for k in range(args.P)]
-        out = torch.empty((args.P, (nb + 15) // 16 * 16) if args.layout == "per_predicate" else (nb * args.P,), dtype=torch.uint8, device="cuda")
+        out = torch.empty((args.P, (nb + 255) // 256 * 256) if args.layout == "per_predicate" else (nb * args.P,), dtype=torch.uint8, device="cuda")
         fn = lambda: eng.shared_scan(keys, col, layout=args.layout, out=out, hits=hits if args.hits else False)  # noqa: E731
         nbytes = n * c / 8 + n / 8 * args.P
     else:

@@ -33,7 +33,7 @@ def main():
         col = eng.generate("splitmix", n, c, 42)
         bitmap = eng.alloc_bitmap(n)
         hits = torch.zeros(8, dtype=torch.int64, device="cuda")
-        stride = (nb + 15) // 16 * 16
+        stride = (nb + 255) // 256 * 256
         out8 = torch.empty((8, stride), dtype=torch.uint8, device="cuda") if "shared_scan" in args.ops else None
         dec = torch.empty(n, dtype=torch.int32, device="cuda") if "decompress" in args.ops else None
         lo, hi = (1 << c) // 4, (1 << c) // 2

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--vpl", default="0", help="shared_vpl values to sweep (0 = the engine's choice, 64, 128)")
     ap.add_argument("--burst", type=int, default=1, help="launches per timed region (back to back: sustained rate)")
     ap.add_argument("--hits", default="1,0", help="1: with hit counts, 0: without")
+    ap.add_argument("--unaligned", action="store_true", help="per-predicate bitmaps at a 16-byte-multiple stride (round 1) instead of whole 128-byte lines")
     args = ap.parse_args()
     import torch
 
@@ -34,7 +35,7 @@ def main():
         keys = [(37 * k + 3) % (1 << c) for k in range(P)]
         for layout in args.layouts.split(","):
             if layout == "per_predicate":
-                out = torch.empty((P, (nb + 15) // 16 * 16), dtype=torch.uint8, device="cuda")
+                out = torch.empty((P, (nb + 255) // 256 * 256 if not args.unaligned else (nb + 15) // 16 * 16), dtype=torch.uint8, device="cuda")
             else:
                 out = torch.empty(nb * P, dtype=torch.uint8, device="cuda")
             hits = torch.zeros(P, dtype=torch.int64, device="cuda")
