@@ -1017,8 +1017,9 @@ const char *mi355_shared_scan_kernel(mi355_ctx *ctx, unsigned c, unsigned P, int
     r.scan.layout = (uint32_t)layout;
     r.scan.hits = with_hits ? &dummy : nullptr;
     if (launch(ctx, r) != MI355_OK) return nullptr;
-    static const char *const names[] = {"shared_lut_kernel", "shared_lut_kernel(multi-pass)", "shared_wide_kernel", "shared_general_kernel"};
-    return choice >= 0 && choice < 4 ? names[choice] : nullptr;
+    static const char *const names[] = {"shared_lut_kernel", "shared_lut_kernel(multi-pass)", "shared_wide_kernel", "shared_general_kernel",
+                                        "shared_linear_kernel"};
+    return choice >= 0 && choice < 5 ? names[choice] : nullptr;
 }
 
 uint64_t mi355_tile_values(unsigned c)

@@ -997,4 +997,157 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
     hits_finalize(a, P, lane);
 }
 
+// ---- shared scan, linear layout, P = 32 .. 1024 a power of two: lanes in memory order ---------------------------------
+// The linear output (byte of 8-value group g and key k at g*P + k, src/simd_scan_shared_linear.cpp:57) of a tile is ONE
+// contiguous block of 512 rows x P bytes.  shared_wide_kernel gives every lane 8 consecutive rows, so a store instruction
+// writes 64 pieces of 16 bytes 8P bytes apart: every 128-byte line is written in 8 or more separate visits, and lines
+// that leave the L2 partly written cost a read-modify-write in ECC-protected HBM (the same effect made per-predicate
+// bitmaps at a non-line-multiple stride up to 2x slower).  Here the 64 lanes of a wave own 64 CONSECUTIVE 32-byte
+// pieces of the output: piece p of the tile = row p / Q, key-quarter p % Q (Q = P / 32 tables of 32 keys), so a wave step
+// writes 2 KiB contiguous with two back-to-back 16-byte stores per lane.  A lane fetches the c bytes of its row from
+// the tile's LDS image (lanes of one row read the same words: broadcast), shifts them into place with byte-granular
+// funnel shifts and decodes the 8 values at compile-time offsets; 8 lookups in ITS quarter's table and one 8 x 32 bit
+// transpose (group form) give the 32 bytes.  Hit counts: per-byte population counts of the 32 result bytes, summed in
+// packed byte counters per lane (a lane keeps its quarter: Q divides 64), flushed to the block's LDS counters per tile.
+// RP = rows per 32-byte piece: 1 for P >= 32 (a piece = 32 keys of one row), 2 for P = 16 (a piece = two whole rows).
+template <int C, int AUX_, int RP>
+__global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a)
+{
+    static_assert(RP == 1 || RP == 2, "RP");
+    constexpr int VPL = 64; // tile geometry of the shared scans: 4096 values = 512 rows of 8
+    using G = ScanGeom<C, VPL>;
+    using L = WideLutGeom<C>;
+    constexpr int AUX = AUX_ & 15;
+    constexpr int ROWS = G::TILE_VALUES / 8;
+    constexpr int RB = RP * C;                // bytes of packed data per piece
+    constexpr int ROW_DW = (RB + 3) / 4;      // dwords holding them once shifted into place
+    constexpr int LOAD_DW = (RB + 3 + 3) / 4; // dwords to fetch: the piece may start at any byte of a dword
+    constexpr int KB = 4 / RP;                // key-bytes (8 keys each) per row inside a piece
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES + 16];
+    __shared__ uint32_t s_hits[kMaxKeys];
+    uint32_t *const lut = (uint32_t *)mi355_dyn_lds; // ceil(P/32) tables of TABLE_BYTES
+    for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxKeys; k += kBlockThreads) s_hits[k] = 0;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t P = a.nkeys;
+    const uint32_t Q = RP == 1 ? P / 32 : 1; // tables of 32 keys per row: 1, 2, 4, ... 32
+    const uint32_t qshift = 31 - __builtin_clz(Q);
+
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+    for (uint32_t i = threadIdx.x; i < Q * L::TABLE_DWORDS; i += kBlockThreads) lut[i] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) {
+        const uint32_t key = (uint32_t)a.keys_dev[k];
+        const bool in_range = C == 32 || (key >> (C & 31)) == 0;
+        if (in_range) {
+#pragma unroll
+            for (int d = 0; d < L::ND; d++) {
+                const uint32_t e = L::SINGLE ? key : L::digit(key, d);
+                __hip_atomic_fetch_or(lut + (k >> 5) * L::TABLE_DWORDS + d * L::ENTRIES + e, 1u << (k & 31), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+
+    // the lane's key-quarter is the same in every step (Q divides 64); its first row advances by 64 RP / Q per step
+    const uint32_t quarter = (uint32_t)lane & (Q - 1);
+    const uint32_t row_first = ((uint32_t)lane >> qshift) * RP;
+    const uint32_t row_step = (64u >> qshift) * RP;
+    const uint32_t nsteps = (uint32_t)ROWS * Q / (64 * RP);
+    const uint32_t *const table = lut + quarter * L::TABLE_DWORDS;
+
+    while (tile < tc.ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // rows of the tile that exist (the ragged tile: fewer, the last one possibly with fewer than 8 values)
+        const uint64_t left = tc.n - tile * G::TILE_VALUES;
+        const uint32_t vals_here = left >= (uint64_t)G::TILE_VALUES ? (uint32_t)G::TILE_VALUES : (uint32_t)left;
+        const uint32_t rows_here = (vals_here + 7) / 8;
+        uint8_t *const out_tile = a.out + tile * (uint64_t)ROWS * P;
+        uint32_t cb[8]; // packed per-byte hit counters of the piece's 32 result bytes (<= 8 per step: flushed every 31 steps)
+#pragma unroll
+        for (int i = 0; i < 8; i++) cb[i] = 0;
+        uint32_t since_flush = 0;
+        auto flush_counts = [&]() {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+#pragma unroll
+                for (int bq = 0; bq < 4; bq++) {
+                    const uint32_t v = (cb[i] >> (8 * bq)) & 0xffu;
+                    // result dword i of the piece holds keys 4 (i mod 2 KB) .. +3 of the lane's table
+                    if (v) atomicAdd(&s_hits[32 * quarter + 4 * (i % (2 * KB)) + bq], v);
+                }
+                cb[i] = 0;
+            }
+            since_flush = 0;
+        };
+#pragma unroll 1
+        for (uint32_t s = 0; s < nsteps; s++) {
+            const uint32_t row = row_first + s * row_step;
+            if (row < rows_here) { // (rows beyond the column: nothing is written)
+                // the piece's RB bytes start at byte row * C of the tile: fetch the dwords around them, shift into place
+                const uint32_t byte0 = row * C;
+                const uint32_t *src = (const uint32_t *)(lds_wave + (byte0 & ~3u));
+                uint32_t d[LOAD_DW];
+#pragma unroll
+                for (int i = 0; i < LOAD_DW; i++) d[i] = src[i];
+                const uint32_t sh = (byte0 & 3u) * 8u;
+                uint32_t w[ROW_DW];
+#pragma unroll
+                for (int i = 0; i < ROW_DW; i++) w[i] = (i + 1 < LOAD_DW) ? __builtin_amdgcn_alignbit(d[i + 1], d[i], sh) : (d[i] >> sh);
+                uint32_t x[8 * RP];
+                extract_all<C, 8 * RP, 0, ROW_DW>(w, x);
+                const uint32_t nvalid = vals_here - row * 8 >= 8 * RP ? 8u * RP : vals_here - row * 8; // short only at the column's end
+                uint32_t y[8];
+#pragma unroll
+                for (int h = 0; h < RP; h++) {
+                    uint32_t m[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        m[i] = L::lookup(table, x[8 * h + i]);
+                        if ((uint32_t)(8 * h + i) >= nvalid) m[i] = 0u;
+                    }
+                    const uint32_t r0[4] = {m[0], m[1], m[2], m[3]}, r1[4] = {m[4], m[5], m[6], m[7]};
+                    uint32_t lo4[4], hi4[4];
+                    transpose4x4_bytes(r0, lo4);
+                    transpose4x4_bytes(r1, hi4);
+#pragma unroll
+                    for (int b = 0; b < KB; b++) {
+                        uint32_t lo = lo4[b], hi = hi4[b];
+                        transpose8x8(lo, hi);
+                        y[2 * KB * h + 2 * b] = lo;
+                        y[2 * KB * h + 2 * b + 1] = hi;
+                    }
+                }
+                u32x4 *dst = (u32x4 *)(out_tile + ((uint64_t)s * 64 + lane) * 32);
+                dst[0] = u32x4{y[0], y[1], y[2], y[3]};
+                // (RP = 2: the second row of the piece; it exists unless the column ends on the first)
+                if (RP == 1 || row + 1 < rows_here) dst[1] = u32x4{y[4], y[5], y[6], y[7]};
+                if (a.hits) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        uint32_t v = y[i];
+                        v = v - ((v >> 1) & 0x55555555u);
+                        v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+                        cb[i] += (v + (v >> 4)) & 0x0F0F0F0Fu;
+                    }
+                }
+            }
+            if (a.hits && ++since_flush == 31) flush_counts();
+        }
+        if (a.hits) flush_counts();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the tile's LDS reads are done: the next DMA may overwrite it
+        const uint64_t next = tile + stride;
+        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        tile = next;
+    }
+    if (a.hits) block_hits_flush(a, s_hits, P);
+    hits_finalize(a, P, lane);
+}
+
 } // namespace mi355

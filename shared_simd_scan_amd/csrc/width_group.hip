@@ -170,7 +170,8 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         // Unlike the single bitmap of launch_scan, these outputs gain nothing from staying in the Infinity Cache.
         const bool nt_stores = r.scan_nt_stores < 0 ? (r.scan.n / 8) * P > (64ull << 20) : r.scan_nt_stores != 0;
         if (r.choice_out) { // introspection (mi355_shared_scan_kernel): which kernel family would run, nothing is launched
-            *r.choice_out = P <= 8 ? 0 : (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) ? 1 : lut_fits<C, VPL>(P) ? 2 : 3;
+            const bool lin_pow2 = linear && P >= 16 && (P & (P - 1)) == 0 && lut_fits<C, VPL>(P) && !(r.scan.flags & 2u);
+            *r.choice_out = P <= 8 ? 0 : lin_pow2 ? 4 : (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) ? 1 : lut_fits<C, VPL>(P) ? 2 : 3;
             break;
         }
         if (P <= 8) { // LDS lookup table, one pass, deferred stores
@@ -183,7 +184,8 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 }
             }
             launch_lut8<C, 64>(r, P, linear);
-        } else if (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) {
+        } else if (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P) &&
+                   !(P >= 16 && (P & (P - 1)) == 0 && lut_fits<C, VPL>(P) && !(r.scan.flags & 2u))) {
             // linear rows of fewer than ~200 keys without hit counts: byte-entry tables, 16 output bytes per round
             // (measured, tools/sweep_p.py, 2.5e8 x 9 bit: P = 16 / 32 / 64 / 128 0.21 / 0.43 / 0.72 / 1.45 ms against
             // 0.41 / 0.58 / 0.91 / 1.50 for the dword-entry kernel, which wins from P = 256: 2.80 against 3.16 ms)
@@ -199,7 +201,16 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
             allow_dynamic_lds<shared_wide_kernel<C, 18, VPL, 0>>(max_dyn, r.device);
             const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : 2;
             const dim3 grid(grid_for(ntiles, want, r.num_cus));
-            if (!linear && !(r.scan.flags & 2u)) { // (flags bit 1: the per-group kernel, for A/B)
+            if (linear && P >= 16 && (P & (P - 1)) == 0 && !(r.scan.flags & 2u)) {
+                // linear rows of 16 .. 1024 keys, a power of two: lanes in memory order (2 KiB contiguous per wave step)
+                allow_dynamic_lds<shared_linear_kernel<C, 2, 1>>(max_dyn, r.device);
+                allow_dynamic_lds<shared_linear_kernel<C, 2, 2>>(max_dyn, r.device);
+                const dim3 lgrid(grid_for(ntiles, r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : 4, r.num_cus));
+                if (P == 16)
+                    hipLaunchKernelGGL((shared_linear_kernel<C, 2, 2>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+                else
+                    hipLaunchKernelGGL((shared_linear_kernel<C, 2, 1>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+            } else if (!linear && !(r.scan.flags & 2u)) { // (flags bit 1: the per-group kernel, for A/B)
                 allow_dynamic_lds<shared_wide2_kernel<C, 2, VPL>>(max_dyn, r.device);
                 allow_dynamic_lds<shared_wide2_kernel<C, 18, VPL>>(max_dyn, r.device);
                 if (nt_stores)

@@ -379,6 +379,33 @@ def test_shared_scan_accepts_any_16_byte_stride(O, eng, L, P):
         assert np.array_equal(hits.cpu().numpy().astype(np.uint64), ohits)
 
 
+@pytest.mark.parametrize("c", [1, 4, 8, 9, 12, 16, 17, 21, 24, 32])
+@pytest.mark.parametrize("P", [16, 32, 64, 256, 1024])
+def test_linear_layout_lanes_in_memory_order(O, eng, L, c, P):
+    """shared_linear_kernel (linear rows of 16 .. 1024 keys, a power of two): every width class, columns ending inside
+    a row (n % 8 != 0), on a row boundary inside a tile, on a tile boundary and inside the first piece; with hit counts
+    (packed byte counters) and without; duplicate and out-of-range keys"""
+    choice = L.mi355_shared_scan_kernel(eng._ctx, c, P, 1, 1)
+    if choice != b"shared_linear_kernel":
+        pytest.skip(f"tables of {P} keys at c={c} do not fit LDS: {choice}")
+    rng = np.random.default_rng(c * 100 + P)
+    for n in (4096 * 3 + 77, 4096 * 2 + 16, 4096 * 2, 5):
+        vals, col = make_column(O, eng, n, c, 6100 + c + P + n)
+        v = vals.astype(np.int64)
+        keys = [int(vals[int(i)]) for i in rng.integers(0, n, size=P)]
+        keys[3] = keys[1]
+        if c < 31:
+            keys[5] = (1 << c) + 2
+        keys32 = [k if k < 2 ** 31 else k - 2 ** 32 for k in keys]
+        nb = (n + 7) // 8
+        expect = np.stack([np_bitmap((v == k) & (k < (1 << c))) for k in keys]).T.reshape(-1)  # [nb, P] row-major
+        for count in (True, False):
+            out, hits = eng.shared_scan(keys32, col, layout="linear", hits=None if count else False)
+            assert np.array_equal(out.cpu().numpy(), expect), (c, P, n, count)
+            if count:
+                assert np.array_equal(hits.cpu().numpy(), np.array([int(((v == k) & (k < (1 << c))).sum()) for k in keys]))
+
+
 def test_out_of_range_keys_never_match(O, eng):
     """SURVEY 8c hazard 5: keys 515, 1027, 65539, -1 on a 9-bit column -> no hits, zero bitmap."""
     import torch
