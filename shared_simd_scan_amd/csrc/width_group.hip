@@ -275,10 +275,12 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
     case kOpDecompress: {
         static const int bpc = blocks_per_cu(decompress_kernel<C, 18>);
         const uint64_t ntiles = (r.decomp.n + DecompGeom<C>::TILE_VALUES - 1) / DecompGeom<C>::TILE_VALUES;
-        // measured with launches back to back (bench.py, 1e9 rows): four blocks per CU 0.863-0.871 ms at c = 9 against
-        // 0.903-0.907 with one (c = 17: 1.01 against 1.10).  Timed one launch at a time it is the other way round by
-        // 2-4 % (the write-back of the tail falls outside the kernel); sustained throughput is what counts.
-        const int want = bpc < 4 ? bpc : 4;
+        // Blocks per CU, launches back to back, 1e9 rows.  Round 1 (one box): four blocks 0.863-0.871 ms at c = 9 against
+        // 0.903-0.907 with one.  Round 2, every width 1..32 on two boxes (profiles/r02_decompress_bpc_sweep.txt): the best
+        // count differs between boxes and widths -- four blocks cost up to 16 % at c <= 8 on one box (c = 8: 0.909 / 0.948 /
+        // 1.055 ms with 1 / 2 / 4), one block costs 6-12 % at c <= 5 on the other -- and TWO is within 2-4 % of the best
+        // almost everywhere on both.
+        const int want = bpc < 2 ? bpc : 2;
         const unsigned grid = grid_for(ntiles, r.max_blocks_per_cu > 0 ? cap_bpc(bpc, r) : want, r.num_cus);
         if (r.dma_aux == 0)
             hipLaunchKernelGGL((decompress_kernel<C, 0>), dim3(grid), dim3(kBlockThreads), 0, r.stream, r.decomp);

@@ -56,6 +56,10 @@ for c in [int(x) for x in args.bits.split(",")]:
         elif args.workload == "scan_and":
             fn = lambda: eng.scan_combine("==", key, col, mask=mask, mask_op="and", bitmap=bm, hits=hits)  # noqa: E731
             nbytes = n * c / 8 + n / 4
+        elif args.workload == "decompress":
+            dec = torch.empty(n, dtype=torch.int32, device="cuda")
+            fn = lambda: eng.decompress(col, out=dec)  # noqa: E731
+            nbytes = n * c / 8 + 4 * n
         elif args.workload == "count":
             fn = lambda: eng.scan_combine("==", key, col, hits=hits, count_only=True)  # noqa: E731
             nbytes = n * c / 8
