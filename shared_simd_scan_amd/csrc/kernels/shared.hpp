@@ -878,8 +878,16 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
     constexpr int NTS = (AUX_ & 32) ? 2 : ((AUX_ & 16) ? 1 : 0); // result stores: 1 non-temporal, 2 write-through (sc1)
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
     __shared__ uint32_t s_hits[kMaxKeys]; // per-block hit counters (block_hits_add8)
+    // Hit counts by HISTOGRAM while 2^C counters fit in LDS: hits[k] = number of values equal to keys[k], whatever P is --
+    // one LDS atomic add per value instead of popcounts + four wave reductions per eight keys and tile (which cost 10-35 %
+    // of the kernel).  The block reads its histogram at the keys once, at the end.  An LDS atomic per value costs ~0.07 ms per
+    // 2.5e8 values whatever P is, the popcount way ~10 % per 32-key round: the histogram pays from four rounds on.
+    constexpr bool HIST = C <= 12;
+    __shared__ uint32_t hist[HIST ? (1 << C) : 1];
     uint32_t *const lut = (uint32_t *)mi355_dyn_lds; // ceil(P/32) * TABLE_BYTES dynamic bytes
     for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxKeys; k += kBlockThreads) s_hits[k] = 0;
+    if constexpr (HIST)
+        for (uint32_t k = threadIdx.x; k < (1u << C); k += kBlockThreads) hist[k] = 0;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -889,6 +897,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
     uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
     const uint32_t P = a.nkeys;
     const uint32_t npass32 = (P + 31) / 32;
+    const bool use_hist = HIST && P >= 128;
 
     if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
 
@@ -922,6 +931,13 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
         extract_all<C, VPL, 0, G::LANE_DWORDS>(w, xs);
         const int64_t left = (int64_t)(tc.n - tile * G::TILE_VALUES) - (int64_t)lane * VPL;
         const int valid = left >= VPL ? VPL : (left <= 0 ? 0 : (int)left);
+        if constexpr (HIST) {
+            if (a.hits && use_hist) {
+#pragma unroll
+                for (int v = 0; v < VPL; v++)
+                    if (full || v < valid) __hip_atomic_fetch_add(&hist[xs[v]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
 
         // (flags bit 2, experiment: every wave starts its round-robin over the 32-key rounds at a different round, so the
         // waves of the lock-stepped grid do not all write the same 32 output streams at the same time)
@@ -959,7 +975,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
             for (int b = 0; b < 4; b++) {
                 const uint32_t pass = p32 * 4 + b;
                 if (pass * 8 < P) {
-                    if (a.hits) {
+                    if (a.hits && !use_hist) {
                         uint32_t cnt[8];
 #pragma unroll
                         for (int q = 0; q < 8; q++) {
@@ -993,6 +1009,15 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
         }
         tile = next;
     }
+    if constexpr (HIST) {
+        if (a.hits && use_hist) {
+            __syncthreads(); // every wave's histogram adds are done
+            for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) {
+                const uint32_t key = (uint32_t)a.keys_dev[k];
+                s_hits[k] = (key >> C) == 0 ? hist[key] : 0u; // keys outside [0, 2^C) match nothing
+            }
+        }
+    }
     if (a.hits) block_hits_flush(a, s_hits, P);
     hits_finalize(a, P, lane);
 }
@@ -1025,8 +1050,12 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
     constexpr int KB = 4 / RP;                // key-bytes (8 keys each) per row inside a piece
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES + 16];
     __shared__ uint32_t s_hits[kMaxKeys];
+    constexpr bool HIST = C <= 12; // hit counts by histogram of the values (see shared_wide2_kernel), else packed byte counters
+    __shared__ uint32_t hist[HIST ? (1 << C) : 1];
     uint32_t *const lut = (uint32_t *)mi355_dyn_lds; // ceil(P/32) tables of TABLE_BYTES
     for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxKeys; k += kBlockThreads) s_hits[k] = 0;
+    if constexpr (HIST)
+        for (uint32_t k = threadIdx.x; k < (1u << C); k += kBlockThreads) hist[k] = 0;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1037,6 +1066,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
     const uint32_t P = a.nkeys;
     const uint32_t Q = RP == 1 ? P / 32 : 1; // tables of 32 keys per row: 1, 2, 4, ... 32
     const uint32_t qshift = 31 - __builtin_clz(Q);
+    const bool use_hist = HIST && P >= 128;
 
     if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
     for (uint32_t i = threadIdx.x; i < Q * L::TABLE_DWORDS; i += kBlockThreads) lut[i] = 0;
@@ -1128,7 +1158,24 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
                 dst[0] = u32x4{y[0], y[1], y[2], y[3]};
                 // (RP = 2: the second row of the piece; it exists unless the column ends on the first)
                 if (RP == 1 || row + 1 < rows_here) dst[1] = u32x4{y[4], y[5], y[6], y[7]};
-                if (a.hits) {
+                if (HIST && use_hist) {
+                    // the Q lanes of a row share the counting of its 8 values: value i belongs to the lane whose table index
+                    // is i mod Q (Q >= 8: one value per lane, picked by a select chain -- one atomic instruction per step)
+                    if (a.hits) {
+                        if (Q >= 8) {
+                            uint32_t xi = x[0];
+#pragma unroll
+                            for (int i = 1; i < 8; i++) xi = quarter == (uint32_t)i ? x[i] : xi;
+                            if (quarter < 8 && quarter < nvalid)
+                                __hip_atomic_fetch_add(&hist[xi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 8 * RP; i++)
+                                if (((uint32_t)i & (Q - 1)) == quarter && (uint32_t)i < nvalid)
+                                    __hip_atomic_fetch_add(&hist[x[i]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                } else if (a.hits) {
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         uint32_t v = y[i];
@@ -1138,13 +1185,22 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
                     }
                 }
             }
-            if (a.hits && ++since_flush == 31) flush_counts();
+            if (!use_hist && a.hits && ++since_flush == 31) flush_counts();
         }
-        if (a.hits) flush_counts();
+        if (!use_hist && a.hits) flush_counts();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the tile's LDS reads are done: the next DMA may overwrite it
         const uint64_t next = tile + stride;
         if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
         tile = next;
+    }
+    if constexpr (HIST) {
+        if (a.hits && use_hist) {
+            __syncthreads(); // every wave's histogram adds are done
+            for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) {
+                const uint32_t key = (uint32_t)a.keys_dev[k];
+                s_hits[k] = (key >> C) == 0 ? hist[key] : 0u; // keys outside [0, 2^C) match nothing
+            }
+        }
     }
     if (a.hits) block_hits_flush(a, s_hits, P);
     hits_finalize(a, P, lane);

@@ -444,17 +444,19 @@ __device__ __forceinline__ void hits_finalize(const ScanArgs &a, uint32_t P, int
     if (threadIdx.x == 0)
         s_ticket = __hip_atomic_fetch_add(a.scratch + kScratchDone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (s_ticket == (unsigned long long)gridDim.x - 1 && threadIdx.x < 64) {
+    if (s_ticket == (unsigned long long)gridDim.x - 1) {
+        // the last block: thread t sums the replicas of keys t, t + 256, ... (consecutive threads = consecutive words of a
+        // replica row; the exchanges of one key are independent, so they overlap -- a single wave walking the keys one
+        // after the other waited a memory-side round trip per key: 0.36 ms at P = 512)
         const uint32_t nslots = gridDim.x < (unsigned)kHitSlots ? gridDim.x : (unsigned)kHitSlots;
-        for (uint32_t k = 0; k < P; k++) {
+        for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) {
             unsigned long long v = 0;
-            if ((uint32_t)lane < nslots)
-                v = __hip_atomic_exchange(a.scratch + lane * kMaxKeys + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0) a.hits[k] = v;
+#pragma unroll 8
+            for (uint32_t sl = 0; sl < nslots; sl++)
+                v += __hip_atomic_exchange(a.scratch + sl * kMaxKeys + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.hits[k] = v;
         }
-        if (lane == 0) __hip_atomic_store(a.scratch + kScratchDone, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(a.scratch + kScratchDone, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

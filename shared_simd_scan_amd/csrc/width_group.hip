@@ -52,7 +52,10 @@ inline int scan_bpc(int occ_bpc, int tile_bytes, const LaunchReq &r)
 }
 
 // static LDS of the multi-pass LUT kernel: four tiles, the per-block hit counters, ticket word and slack
-template <int C, int VPL> constexpr size_t lut_static_lds() { return 4 * ScanGeom<C, VPL>::LDS_BYTES + kMaxKeys * 4 + 512; }
+template <int C, int VPL> constexpr size_t lut_static_lds()
+{
+    return 4 * ScanGeom<C, VPL>::LDS_BYTES + kMaxKeys * 4 + 512 + (C <= 12 ? (size_t)(4u << C) : 16); // + the hit-count histogram
+}
 
 // the 32-keys-per-lookup kernel needs ceil(P/32) tables next to that in the CU's 160 KiB of LDS
 template <int C, int VPL> bool lut_fits(uint32_t P)
@@ -170,7 +173,8 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         // Unlike the single bitmap of launch_scan, these outputs gain nothing from staying in the Infinity Cache.
         const bool nt_stores = r.scan_nt_stores < 0 ? (r.scan.n / 8) * P > (64ull << 20) : r.scan_nt_stores != 0;
         if (r.choice_out) { // introspection (mi355_shared_scan_kernel): which kernel family would run, nothing is launched
-            const bool lin_pow2 = linear && P >= 16 && (P & (P - 1)) == 0 && lut_fits<C, VPL>(P) && !(r.scan.flags & 2u);
+            const bool lin_pow2 = linear && P >= 16 && (P & (P - 1)) == 0 && lut_fits<C, VPL>(P) && !(r.scan.flags & 2u) &&
+                                  (2 * ((size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES + lut_static_lds<C, VPL>()) <= 160 * 1024 || r.scan.hits);
             *r.choice_out = P <= 8 ? 0 : lin_pow2 ? 4 : (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) ? 1 : lut_fits<C, VPL>(P) ? 2 : 3;
             break;
         }
@@ -201,7 +205,10 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
             allow_dynamic_lds<shared_wide_kernel<C, 18, VPL, 0>>(max_dyn, r.device);
             const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : 2;
             const dim3 grid(grid_for(ntiles, want, r.num_cus));
-            if (linear && P >= 16 && (P & (P - 1)) == 0 && !(r.scan.flags & 2u)) {
+            // (it needs two blocks per CU to hide its lookups: tables too big for that -- P = 1024 at c <= 10 -- stay on the
+            // per-group kernel unless hit counts are wanted: 2.5e8 x 9 bit, P = 1024: 13.5 against 10.2 ms without, 15.6 against 17.8 with)
+            const bool lin_two_blocks = 2 * (dyn + lut_static_lds<C, VPL>()) <= 160 * 1024 || r.scan.hits != nullptr;
+            if (linear && P >= 16 && (P & (P - 1)) == 0 && lin_two_blocks && !(r.scan.flags & 2u)) {
                 // linear rows of 16 .. 1024 keys, a power of two: lanes in memory order (2 KiB contiguous per wave step)
                 allow_dynamic_lds<shared_linear_kernel<C, 2, 1>>(max_dyn, r.device);
                 allow_dynamic_lds<shared_linear_kernel<C, 2, 2>>(max_dyn, r.device);
