@@ -116,12 +116,22 @@ int main(int argc, char **argv)
         constexpr int VPL = scan_vpl(C, kModeEq);
         using G = ScanGeom<C, VPL>;
         const uint64_t ntiles = (n + G::TILE_VALUES - 1) / G::TILE_VALUES;
-        vs.push_back({"scan_eq (product, plain st)", [=](int bpc, hipStream_t s) {
+        vs.push_back({"scan_eq (round-1 kernel, plain st)", [=](int bpc, hipStream_t s) {
                           hipLaunchKernelGGL((scan_kernel<C, kModeEq, 2, VPL>), dim3(grid_of(ntiles, bpc)), dim3(kBlockThreads), 0, s, sa);
                       }, {1, 2}, read_bytes + n / 8.0});
-        vs.push_back({"scan_eq (product, sc1 st)", [=](int bpc, hipStream_t s) {
+        vs.push_back({"scan_eq (round-1 kernel, sc1 st)", [=](int bpc, hipStream_t s) {
                           hipLaunchKernelGGL((scan_kernel<C, kModeEq, 34, VPL>), dim3(grid_of(ntiles, bpc)), dim3(kBlockThreads), 0, s, sa);
                       }, {1, 2}, read_bytes + n / 8.0});
+        // the shipped kernel: 4 tiles per store burst (K = 1 at the widths where burst_k() says so: see width_group.hip)
+        constexpr int KB = (C == 5 || C == 6 || (C >= 9 && C <= 16)) ? 4 : 1;
+        vs.push_back({"scan_eq (product: burst, sc1 st)", [=](int bpc, hipStream_t s) {
+                          hipLaunchKernelGGL((scan_burst_kernel<C, kModeEq, 34, VPL, KB>), dim3(grid_of((ntiles + KB - 1) / KB, bpc)), dim3(kBlockThreads), 0, s, sa);
+                      }, {1, 2}, read_bytes + n / 8.0});
+        ScanArgs sc = sa;
+        sc.out = nullptr;
+        vs.push_back({"scan_eq count only (product)", [=](int bpc, hipStream_t s) {
+                          hipLaunchKernelGGL((scan_burst_kernel<C, kModeEq, 34, VPL, KB>), dim3(grid_of((ntiles + KB - 1) / KB, bpc)), dim3(kBlockThreads), 0, s, sc);
+                      }, {1, 2}, read_bytes});
     }
     {
         constexpr int VPL = scan_vpl(C, kModeRange);
