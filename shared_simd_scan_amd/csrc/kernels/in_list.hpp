@@ -21,6 +21,7 @@ __global__ __launch_bounds__(kBlockThreads) void in_kernel(ScanArgs a)
     constexpr int SET_BYTES = BITSET ? ((1 << (C < 16 ? C : 16)) + 7) / 8 : 16;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
     __shared__ __attribute__((aligned(16))) uint32_t set_words[(SET_BYTES + 3) / 4];
+    __shared__ __attribute__((aligned(16))) uint8_t mlds[kWavesPerBlock][1024]; // the tile's AND-mask bytes (LDS-DMA, with the tile)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -29,8 +30,18 @@ __global__ __launch_bounds__(kBlockThreads) void in_kernel(ScanArgs a)
     const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
     uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
     const uint32_t P = a.nkeys;
+    uint8_t *mlds_wave = mlds[wave];
+    // the mask of a fused conjunction travels with the tile (in front of it, so one wait covers both): a plain load issued
+    // where the mask is needed stalled every tile for a memory round trip (see scan_burst_kernel)
+    auto issue_tile = [&](uint64_t t) {
+        if (a.and_mask && t < tc.nfull) {
+            if (lane * 16 < G::BITMAP_BYTES)
+                __builtin_amdgcn_global_load_lds(MI355_GPTR(a.and_mask + t * G::BITMAP_BYTES + lane * 16), MI355_LPTR(mlds_wave), 16, 0, 0);
+        }
+        tc.template issue<AUX>(a.packed, t, lds_wave, lane);
+    };
 
-    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+    if (tile < tc.ntiles) issue_tile(tile);
     if constexpr (BITSET) {
         for (uint32_t i = threadIdx.x; i < (SET_BYTES + 3) / 4; i += kBlockThreads) set_words[i] = 0;
         __syncthreads();
@@ -50,10 +61,15 @@ __global__ __launch_bounds__(kBlockThreads) void in_kernel(ScanArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t w[G::LANE_DWORDS];
         read_lane_data<C, VPL>(lds_wave, lane, w);
+        uint32_t mcur[WORDS];
+        if (a.and_mask && tile < tc.nfull) {
+#pragma unroll
+            for (int j = 0; j < WORDS; j++) mcur[j] = ((const uint32_t *)(mlds_wave + lane * (WORDS * 4)))[j];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (prev != ~0ull) store_words<WORDS, NTS>(out_lane + prev * G::BITMAP_BYTES, res);
         const uint64_t next = tile + stride;
-        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        if (next < tc.ntiles) issue_tile(next);
 
         uint32_t xs[VPL];
         extract_all<C, VPL, 0, G::LANE_DWORDS>(w, xs);
@@ -91,9 +107,8 @@ __global__ __launch_bounds__(kBlockThreads) void in_kernel(ScanArgs a)
         for (int j = 0; j < WORDS; j++) res[j] ^= inv;
         if (tile < tc.nfull) {
             if (a.and_mask) {
-                const uint32_t *mp = (const uint32_t *)(a.and_mask + tile * G::BITMAP_BYTES + lane * (WORDS * 4));
 #pragma unroll
-                for (int j = 0; j < WORDS; j++) res[j] &= mp[j];
+                for (int j = 0; j < WORDS; j++) res[j] &= mcur[j];
             }
 #pragma unroll
             for (int j = 0; j < WORDS; j++) hits += __builtin_popcount(res[j]);

@@ -881,7 +881,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
     // Hit counts by HISTOGRAM while 2^C counters fit in LDS: hits[k] = number of values equal to keys[k], whatever P is --
     // one LDS atomic add per value instead of popcounts + four wave reductions per eight keys and tile (which cost 10-35 %
     // of the kernel).  The block reads its histogram at the keys once, at the end.  An LDS atomic per value costs ~0.07 ms per
-    // 2.5e8 values whatever P is, the popcount way ~10 % per 32-key round: the histogram pays from four rounds on.
+    // 2.5e8 values whatever P is, the popcount way 0.05-0.07 ms per 32-key round: the histogram pays from two rounds on.
     constexpr bool HIST = C <= 12;
     __shared__ uint32_t hist[HIST ? (1 << C) : 1];
     uint32_t *const lut = (uint32_t *)mi355_dyn_lds; // ceil(P/32) * TABLE_BYTES dynamic bytes
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
     uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
     const uint32_t P = a.nkeys;
     const uint32_t npass32 = (P + 31) / 32;
-    const bool use_hist = HIST && P >= 128;
+    const bool use_hist = HIST && P >= 64;
 
     if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
 
