@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 2 evidence: rocprofv3 stats + PMC per workload, width sweep, P sweep, next-row bench, host path
+# tools/evidence.sh -- the evidence set of a round (run through gpurun): rocprofv3 stats + PMC per workload (tools/profile.sh),
+# width sweep, P sweep, next-row bench, host-path rates, bench lines.  Outputs under gpurun_out/; summarise with
+# tools/summarize_profile.py gpurun_out/prof_<tag>_<workload> <workload> <tag> 1000000000 9 and copy into profiles/.
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r2h; mkdir -p $O
