@@ -92,6 +92,25 @@ MI355_API int mi355_ctx_set_stream(mi355_ctx *ctx, void *hip_stream);
  * the Infinity Cache, non-temporal beyond), 0 plain, 1 non-temporal, 2 write-through) */
 MI355_API int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value);
 
+/* ---- load-time tuning (optional) ----------------------------------------------------------------------------------
+ * The resident blocks per CU at which the streaming kernels run fastest differ between MI355X boxes for the same
+ * binary by 3-10 %.  mi355_tune_dev measures 1 / 2 / 4 blocks per CU on the caller's own resident column (`what` = a
+ * mask of MI355_TUNE_* bits: equality + range scans, their count-only forms, the fused-mask scan, decompress), with
+ * launches back to back as a query stream issues them, and keeps the winners in the context: later launches of that
+ * kind and width over >= 5e7 rows use them ("max_blocks_per_cu", when set, still wins).  It BLOCKS (synchronises the
+ * context's stream; about 40 launches per kind), uses the context's pooled scratch for its outputs, and never changes
+ * any result.  Columns below 5e7 rows: returns MI355_OK without measuring.  Call it once per width after loading. */
+enum {
+    MI355_TUNE_SCAN = 1,
+    MI355_TUNE_COUNT = 2,
+    MI355_TUNE_MASK = 4,
+    MI355_TUNE_DECOMPRESS = 8,
+    MI355_TUNE_ALL = 15
+};
+MI355_API int mi355_tune_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, unsigned what);
+/* what mi355_tune_dev kept for one kind (ONE MI355_TUNE_* bit; range != 0: the range-scan kernel), 0 = not tuned */
+MI355_API int mi355_tuned_blocks_per_cu(mi355_ctx *ctx, unsigned c, unsigned what, int range);
+
 /* ---- buffer sizing, in bytes.  replaces: compressed_buffer_size / decompression_output_buffer_size
  * / scan_output_buffer_size (src/simd_scan.hpp:20-40), same formulas. -------------------------- */
 MI355_API size_t mi355_compressed_buffer_size(unsigned c, size_t n);

@@ -25,6 +25,8 @@ SYMBOLS = [
     ("mi355_device_count", _int, [C.POINTER(_int)]),
     ("mi355_ctx_set_option", _int, [_vp, C.c_char_p, _int]),
     ("mi355_ctx_set_stream", _int, [_vp, _vp]),
+    ("mi355_tune_dev", _int, [_vp, _vp, _u64, C.c_uint, C.c_uint]),
+    ("mi355_tuned_blocks_per_cu", _int, [_vp, C.c_uint, C.c_uint, _int]),
     ("mi355_shard_rows", _int, [_u64, C.c_uint, C.c_uint, C.POINTER(_u64), C.POINTER(_u64)]),
     ("mi355_compressed_buffer_size", _sz, [C.c_uint, _sz]),
     ("mi355_decompression_output_buffer_size", _sz, [_sz]),

@@ -103,6 +103,15 @@ typedef hipError_t (*group_fn)(const LaunchReq &);
 const group_fn kGroups[kNumGroups] = {launch_group_0, launch_group_1, launch_group_2, launch_group_3,
                                       launch_group_4, launch_group_5, launch_group_6, launch_group_7};
 
+// rows from which a launch uses what mi355_tune_dev measured (smaller columns take microseconds whatever the grid)
+constexpr uint64_t kTuneMinRows = 50000000ull;
+
+// one entry per kernel shape: op, width, and for the scans whether a bitmap is written and whether a mask is read
+inline uint32_t tune_key(int op, unsigned c, bool writes_bitmap, bool reads_mask)
+{
+    return (uint32_t)op * 64u + c + (writes_bitmap ? 0u : 1u << 12) + (reads_mask ? 1u << 13 : 0u);
+}
+
 int launch(mi355_ctx *ctx, LaunchReq &r)
 {
     if (int rc = bind(ctx)) return rc;
@@ -116,6 +125,14 @@ int launch(mi355_ctx *ctx, LaunchReq &r)
     r.scan_burst = ctx->scan_burst;
     r.scan.flags = ctx->kernel_flags;
     r.scan.scratch = ctx->kernel_scratch;
+    if (r.max_blocks_per_cu == 0 && !ctx->tuned_bpc.empty()) {
+        const bool scan = r.op == kOpScanEq || r.op == kOpScanRange;
+        if ((scan && r.scan.n >= kTuneMinRows) || (r.op == kOpDecompress && r.decomp.n >= kTuneMinRows)) {
+            const auto it = ctx->tuned_bpc.find(scan ? tune_key(r.op, r.c, r.scan.out != nullptr, r.scan.and_mask != nullptr)
+                                                     : tune_key(r.op, r.c, true, false));
+            if (it != ctx->tuned_bpc.end()) r.max_blocks_per_cu = it->second;
+        }
+    }
     hipError_t e = kGroups[(r.c - 1) / 4](r);
     if (e != hipSuccess) return fail(MI355_E_HIP, "kernel launch (op %d, c=%u): %s", r.op, r.c, hipGetErrorString(e));
     return MI355_OK;
@@ -877,6 +894,102 @@ static int upload_packed(mi355_ctx *ctx, const void *packed_host, uint64_t n, un
     HIP_TRY(hipMemcpyAsync(*dp, packed_host, payload, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync((uint8_t *)*dp + payload, 0, 16, ctx->stream));
     return MI355_OK;
+}
+
+// ---- load-time tuning ------------------------------------------------------------------------------------------
+// The resident blocks per CU at which the streaming kernels run fastest differ between MI355X boxes for the SAME
+// binary (equality scan, c = 9: two blocks 3-5 % ahead of one on two boxes, 5 % behind on a third; decompress:
+// profiles/r02_decompress_bpc_sweep.txt), so a static default leaves a few per cent behind somewhere.  This call
+// measures 1 / 2 / 4 blocks per CU on the caller's own column, back to back as a query stream would issue them
+// (isolated launches between event pairs rank the candidates differently), and keeps the winners in the context.
+int mi355_tune_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, unsigned what)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    CtxLock lk(ctx->mu);
+    if ((rc = check_width(c))) return rc;
+    if (!packed_dev || ((uintptr_t)packed_dev & 15)) return fail(MI355_E_INVALID, "packed_dev must be a 16-byte aligned device pointer");
+    if (what == 0 || (what & ~(unsigned)MI355_TUNE_ALL)) return fail(MI355_E_INVALID, "what=%u: a mask of MI355_TUNE_* bits", what);
+    if (n < kTuneMinRows) return MI355_OK; // nothing to learn: such launches never consult the table
+    if ((rc = bind(ctx))) return rc;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+        return fail(MI355_E_INVALID, "mi355_tune_dev synchronises: not while the stream is being captured");
+    const size_t stride = mi355_bitmap_stride(n);
+    void *bitmaps = nullptr, *values = nullptr;
+    if ((rc = pool_get(ctx, mi355_ctx::kPoolOut, 2 * stride, &bitmaps))) return rc;
+    uint8_t *bitmap = (uint8_t *)bitmaps, *mask = bitmap + stride;
+    const uint64_t decomp_rows = n < (1ull << 28) ? n : (1ull << 28); // 1 GiB of output is plenty to rank the grids
+    if ((what & MI355_TUNE_DECOMPRESS) && (rc = pool_get(ctx, mi355_ctx::kPoolAux, decomp_rows * 4 + 64, &values))) return rc;
+    uint64_t *hits = (uint64_t *)ctx->hits_scratch;
+    const uint32_t top = c >= 32 ? 0xffffffffu : (1u << c) - 1;
+    const uint32_t lo = top / 4, hi = top / 2;
+    HIP_TRY(hipMemsetAsync(mask, 0x5a, stride, ctx->stream));
+    struct Shape {
+        unsigned bit;
+        int op;
+        bool bitmap, mask;
+    };
+    // (mi355_scan_combine_dev and everything built on it -- count-only, fused masks, comparisons -- run the range kernel)
+    const Shape shapes[] = {{MI355_TUNE_SCAN, kOpScanEq, true, false},
+                            {MI355_TUNE_SCAN, kOpScanRange, true, false},
+                            {MI355_TUNE_COUNT, kOpScanRange, false, false},
+                            {MI355_TUNE_MASK, kOpScanRange, true, true},
+                            {MI355_TUNE_DECOMPRESS, kOpDecompress, true, false}};
+    const int cands[3] = {1, 2, 4};
+    constexpr int kRounds = 3, kBurst = 6;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return fail(MI355_E_HIP, "hipEventCreate failed");
+    }
+    const int saved = ctx->max_blocks_per_cu;
+    for (const Shape &sh : shapes) {
+        if (!(what & sh.bit)) continue;
+        auto once = [&]() -> int {
+            if (sh.op == kOpDecompress) return mi355_decompress_dev(ctx, packed_dev, decomp_rows, c, (int32_t *)values);
+            if (sh.op == kOpScanEq) return mi355_scan_eq_dev(ctx, packed_dev, n, c, (int32_t)lo, bitmap, hits);
+            return mi355_scan_combine_dev(ctx, packed_dev, n, c, MI355_CMP_BETWEEN, lo, hi, MI355_BITMAP_AND, sh.mask ? mask : nullptr,
+                                          sh.bitmap ? bitmap : nullptr, hits);
+        };
+        float best[3] = {0, 0, 0};
+        for (int round = 0; round < kRounds && rc == MI355_OK; round++)
+            for (int k = 0; k < 3 && rc == MI355_OK; k++) {
+                ctx->max_blocks_per_cu = cands[k];
+                rc = once(); // the first launch after a change of grid is not timed
+                if (rc == MI355_OK && hipEventRecord(e0, ctx->stream) != hipSuccess) rc = fail(MI355_E_HIP, "hipEventRecord failed");
+                for (int i = 0; i < kBurst && rc == MI355_OK; i++) rc = once();
+                if (rc == MI355_OK && (hipEventRecord(e1, ctx->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess))
+                    rc = fail(MI355_E_HIP, "hipEventSynchronize failed");
+                float ms = 0;
+                if (rc == MI355_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && (round == 0 || ms < best[k])) best[k] = ms;
+            }
+        ctx->max_blocks_per_cu = saved;
+        if (rc != MI355_OK) break;
+        int win = 0;
+        for (int k = 1; k < 3; k++)
+            if (best[k] < best[win] * 0.995f) win = k; // a later candidate has to win by more than the timer's noise
+        ctx->tuned_bpc[tune_key(sh.op, c, sh.bitmap, sh.mask)] = cands[win];
+    }
+    ctx->max_blocks_per_cu = saved;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int mi355_tuned_blocks_per_cu(mi355_ctx *ctx, unsigned c, unsigned what, int range)
+{
+    if (resolve(ctx)) return 0;
+    CtxLock lk(ctx->mu);
+    uint32_t key;
+    if (what == MI355_TUNE_SCAN) key = tune_key(range ? kOpScanRange : kOpScanEq, c, true, false);
+    else if (what == MI355_TUNE_COUNT) key = tune_key(kOpScanRange, c, false, false);
+    else if (what == MI355_TUNE_MASK) key = tune_key(kOpScanRange, c, true, true);
+    else if (what == MI355_TUNE_DECOMPRESS) key = tune_key(kOpDecompress, c, true, false);
+    else return 0;
+    const auto it = ctx->tuned_bpc.find(key);
+    return it == ctx->tuned_bpc.end() ? 0 : it->second;
 }
 
 int mi355_decompress(mi355_ctx *ctx, const void *packed_host, uint64_t n, unsigned c, int32_t *out_host)

@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <map>
 #include <mutex>
 #include <string>
 
@@ -19,6 +20,8 @@ struct mi355_ctx {
     int scan_nt_stores = -1; // -1: by bitmap size (see width_group.hip), 0 plain, 1 non-temporal
     int shared_vpl = 0;  // 0: engine's choice
     unsigned kernel_flags = 0; // experiment switches handed to the kernels (ScanArgs::flags)
+    // mi355_tune_dev: blocks per CU measured on THIS device for the large streaming launches; key = tune_key() in capi.hip
+    std::map<uint32_t, int> tuned_bpc;
     int scan_burst = 0;  // 0: tiles per store burst by width; 1: one tile per burst
     int dma_aux = 18; // bits 0-3: policy of the HBM->LDS loads (2 = non-temporal: the column is streamed once);
                       // bit 4: non-temporal stores in decompress

@@ -81,6 +81,23 @@ class ScanEngine:
     def set_option(self, name: str, value: int) -> None:
         check(lib().mi355_ctx_set_option(self._ctx, name.encode(), int(value)))
 
+    TUNE_KINDS = {"scan": 1, "count": 2, "mask": 4, "decompress": 8, "all": 15}
+
+    def tune(self, col: "PackedColumn", what: str = "all") -> dict:
+        """mi355_tune_dev: measure 1 / 2 / 4 resident blocks per CU on this column (>= 5e7 rows; blocks) and keep the
+        fastest for later launches of that kind and width.  Returns what was kept ({} for a small column)."""
+        mask = 0
+        for kind in what.split("+"):
+            mask |= self.TUNE_KINDS[kind]
+        check(lib().mi355_tune_dev(self._ctx, col.data.data_ptr(), col.n, col.c, mask))
+        return self.tuned(col.c)
+
+    def tuned(self, c: int) -> dict:
+        got = {"scan_eq": lib().mi355_tuned_blocks_per_cu(self._ctx, c, 1, 0), "scan_range": lib().mi355_tuned_blocks_per_cu(self._ctx, c, 1, 1),
+               "count": lib().mi355_tuned_blocks_per_cu(self._ctx, c, 2, 0), "mask": lib().mi355_tuned_blocks_per_cu(self._ctx, c, 4, 0),
+               "decompress": lib().mi355_tuned_blocks_per_cu(self._ctx, c, 8, 0)}
+        return {k: v for k, v in got.items() if v}
+
     def use_stream(self, stream: torch.cuda.Stream) -> None:
         """enqueue subsequent work on `stream` (e.g. the capture stream inside torch.cuda.graph)"""
         self.stream = stream

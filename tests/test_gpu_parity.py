@@ -717,6 +717,82 @@ def test_one_tile_per_burst_option_agrees(O, eng, c):
     assert np.array_equal(r4.cpu().numpy(), orb) and np.array_equal(r1.cpu().numpy(), orb) and int(hr4.item()) == orh == int(hr1.item())
 
 
+@pytest.mark.parametrize("c", [2, 9, 21])
+def test_online_blocks_per_cu_choice_never_changes_results(O, eng, c):
+    """columns of >= 5e7 rows take part in the online choice of blocks per CU (ctx.hpp mi355_tuner): the first launches
+    alternate between 1 / 2 / 4 blocks per CU, then one is kept.  Every launch of the tuning phase and after it gives the
+    bytes of the static-default launch, for the scans (bitmap, count-only, fused mask) and for decompress."""
+    import torch
+
+    n = 50_000_000 + 12_345
+    col = eng.generate("splitmix", n, c, 600 + c)
+    key = 1
+    try:
+        eng.set_option("autotune", 0)
+        bm0, h0 = eng.scan(key, col)
+        r0, hr0 = eng.scan_range(1, (1 << c) // 2, col)
+        m0, hm0 = eng.scan_combine("==", key, col, mask=r0, mask_op="or")
+        d0 = eng.decompress(col)
+        eng.set_option("autotune", 2)  # forget anything learnt, tuning on
+        bm, r, m = eng.alloc_bitmap(n), eng.alloc_bitmap(n), eng.alloc_bitmap(n)
+        d = torch.empty_like(d0)
+        hits = torch.zeros(4, dtype=torch.int64, device="cuda")
+        for it in range(24):  # 3 candidates x 5 samples, then settled launches
+            eng.scan(key, col, bitmap=bm, hits=hits[0:1])
+            eng.scan_range(1, (1 << c) // 2, col, bitmap=r, hits=hits[1:2])
+            eng.scan_combine("==", key, col, mask=r0, mask_op="or", bitmap=m, hits=hits[2:3])
+            eng.scan_combine("==", key, col, hits=hits[3:4], count_only=True)
+            eng.decompress(col, out=d)
+            if it % 4 == 3 or it < 4:
+                assert torch.equal(bm, bm0) and torch.equal(r, r0) and torch.equal(m, m0) and torch.equal(d, d0), it
+                assert hits.tolist() == [int(h0.item()), int(hr0.item()), int(hm0.item()), int(h0.item())], it
+                bm.zero_(), r.zero_(), m.zero_(), d.zero_(), hits.zero_()
+    finally:
+        eng.set_option("autotune", 1)
+    # pinned against the oracle once (the rest of the suite covers the kernels themselves)
+    obm, ohits = O.scan_eq(col.data.cpu().numpy(), n, c, key)
+    assert np.array_equal(bm0.cpu().numpy(), obm) and int(h0.item()) == ohits
+
+
+@pytest.mark.parametrize("c", [1, 9, 21, 32])
+def test_load_time_tuning_never_changes_results(O, c):
+    """mi355_tune_dev measures 1 / 2 / 4 blocks per CU on a resident column of >= 5e7 rows and keeps the fastest per
+    kind; every kind gives the bytes it gave before tuning, and a small column is left alone"""
+    import torch
+
+    from shared_simd_scan_amd import ScanEngine
+
+    eng = ScanEngine(0)  # own context: what it learns must not leak into the other tests' engine
+    n = 50_000_000 + 12_345
+    col = eng.generate("splitmix", n, c, 600 + c)
+    key, lo, hi = 1, 0, max(1, ((1 << c) - 1) // 2)
+    before = (eng.scan(key, col), eng.scan_range(lo, hi, col), eng.scan_combine("<=", hi, col, count_only=True)[1])
+    mask = before[1][0]
+    before += (eng.scan_combine("==", key, col, mask=mask, mask_op="or"), eng.decompress(col))
+    assert eng.tuned(c) == {}
+    small = eng.generate("splitmix", 1_000_000, c, 1)
+    assert eng.tune(small) == {}
+    kept = eng.tune(col)
+    assert set(kept) == {"scan_eq", "scan_range", "count", "mask", "decompress"} and all(v in (1, 2, 4) for v in kept.values()), kept
+    after = (eng.scan(key, col), eng.scan_range(lo, hi, col), eng.scan_combine("<=", hi, col, count_only=True)[1],
+             eng.scan_combine("==", key, col, mask=mask, mask_op="or"), eng.decompress(col))
+    for b, a in zip(before, after):
+        if isinstance(b, tuple):
+            assert torch.equal(b[0], a[0]) and int(b[1].item()) == int(a[1].item())
+        else:
+            assert torch.equal(b, a)
+    obm, ohits = O.scan_eq(col.data.cpu().numpy(), n, c, key)
+    assert np.array_equal(after[0][0].cpu().numpy(), obm) and int(after[0][1].item()) == ohits
+    with pytest.raises(Exception):
+        lib_tune_bad(eng, col)
+
+
+def lib_tune_bad(eng, col):
+    from shared_simd_scan_amd._capi import check, lib
+
+    check(lib().mi355_tune_dev(eng._ctx, col.data.data_ptr(), col.n, col.c, 0))  # what = 0: invalid
+
+
 @pytest.mark.parametrize("c", [1, 4, 5, 7, 9, 13, 14, 16, 17, 21, 32])
 @pytest.mark.parametrize("n", [1, 77, 8192, 8192 * 16 + 5, 8192 * 16 * 5 + 4097, 1_000_003])
 def test_scan_select_matches_numpy(O, eng, c, n):
