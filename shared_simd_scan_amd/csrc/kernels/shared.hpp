@@ -882,6 +882,8 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
     // one LDS atomic add per value instead of popcounts + four wave reductions per eight keys and tile (which cost 10-35 %
     // of the kernel).  The block reads its histogram at the keys once, at the end.  An LDS atomic per value costs ~0.07 ms per
     // 2.5e8 values whatever P is, the popcount way 0.05-0.07 ms per 32-key round: the histogram pays from two rounds on.
+    // P <= 32 (one round of 32 keys): neither -- every key's count lives in a register of the lane for the whole launch
+    // (v_bcnt_u32_b32 accumulates: two operations per key and tile), reduced over the wave once at the end.
     constexpr bool HIST = C <= 12;
     __shared__ uint32_t hist[HIST ? (1 << C) : 1];
     uint32_t *const lut = (uint32_t *)mi355_dyn_lds; // ceil(P/32) * TABLE_BYTES dynamic bytes
@@ -897,7 +899,13 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
     uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
     const uint32_t P = a.nkeys;
     const uint32_t npass32 = (P + 31) / 32;
+    const bool reg_counts = npass32 == 1 && !(a.flags & 8u); // (flags bit 3: the per-tile wave reductions, for A/B)
     const bool use_hist = HIST && P >= 64;
+    uint32_t acc[4][8];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc[b][q] = 0;
 
     if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
 
@@ -975,7 +983,12 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
             for (int b = 0; b < 4; b++) {
                 const uint32_t pass = p32 * 4 + b;
                 if (pass * 8 < P) {
-                    if (a.hits && !use_hist) {
+                    if (a.hits && reg_counts) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++)
+#pragma unroll
+                            for (int j = 0; j < WORDS; j++) acc[b][q] += __builtin_popcount(outw[b][q][j]);
+                    } else if (a.hits && !use_hist) {
                         uint32_t cnt[8];
 #pragma unroll
                         for (int q = 0; q < 8; q++) {
@@ -1008,6 +1021,23 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
             }
         }
         tile = next;
+    }
+    if (a.hits && reg_counts) {
+        // a lane's count is below 2^32 (it sees at most n / 64 values); the wave's sum need not be: reduce in 64 bits
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if ((uint32_t)(8 * b + q) < P) {
+                    const uint32_t lo = wave_sum(acc[b][q] & 0xffffu), hi = wave_sum(acc[b][q] >> 16);
+                    if (lane == 0) {
+                        const unsigned long long v = (unsigned long long)lo + ((unsigned long long)hi << 16);
+                        if (v)
+                            __hip_atomic_fetch_add(a.scratch + (blockIdx.x % kHitSlots) * kMaxKeys + 8 * b + q, v, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
     }
     if constexpr (HIST) {
         if (a.hits && use_hist) {
@@ -1091,6 +1121,26 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
     const uint32_t row_step = (64u >> qshift) * RP;
     const uint32_t nsteps = (uint32_t)ROWS * Q / (64 * RP);
     const uint32_t *const table = lut + quarter * L::TABLE_DWORDS;
+    // packed per-byte hit counters of the piece's 32 result bytes: at most 8 per step, so they are flushed to the block's
+    // LDS counters every 31 steps -- counted ACROSS tiles (a tile is only 4 steps at P = 16, 8 at P = 32: flushing per
+    // tile cost 32 LDS atomics per lane every 4 steps, a third of the kernel's time with hit counts)
+    uint32_t cb[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cb[i] = 0;
+    uint32_t since_flush = 0;
+    auto flush_counts = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#pragma unroll
+            for (int bq = 0; bq < 4; bq++) {
+                const uint32_t v = (cb[i] >> (8 * bq)) & 0xffu;
+                // result dword i of the piece holds keys 4 (i mod 2 KB) .. +3 of the lane's table
+                if (v) atomicAdd(&s_hits[32 * quarter + 4 * (i % (2 * KB)) + bq], v);
+            }
+            cb[i] = 0;
+        }
+        since_flush = 0;
+    };
 
     while (tile < tc.ntiles) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1099,23 +1149,6 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
         const uint32_t vals_here = left >= (uint64_t)G::TILE_VALUES ? (uint32_t)G::TILE_VALUES : (uint32_t)left;
         const uint32_t rows_here = (vals_here + 7) / 8;
         uint8_t *const out_tile = a.out + tile * (uint64_t)ROWS * P;
-        uint32_t cb[8]; // packed per-byte hit counters of the piece's 32 result bytes (<= 8 per step: flushed every 31 steps)
-#pragma unroll
-        for (int i = 0; i < 8; i++) cb[i] = 0;
-        uint32_t since_flush = 0;
-        auto flush_counts = [&]() {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-#pragma unroll
-                for (int bq = 0; bq < 4; bq++) {
-                    const uint32_t v = (cb[i] >> (8 * bq)) & 0xffu;
-                    // result dword i of the piece holds keys 4 (i mod 2 KB) .. +3 of the lane's table
-                    if (v) atomicAdd(&s_hits[32 * quarter + 4 * (i % (2 * KB)) + bq], v);
-                }
-                cb[i] = 0;
-            }
-            since_flush = 0;
-        };
 #pragma unroll 1
         for (uint32_t s = 0; s < nsteps; s++) {
             const uint32_t row = row_first + s * row_step;
@@ -1187,12 +1220,12 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
             }
             if (!use_hist && a.hits && ++since_flush == 31) flush_counts();
         }
-        if (!use_hist && a.hits) flush_counts();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the tile's LDS reads are done: the next DMA may overwrite it
         const uint64_t next = tile + stride;
         if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
         tile = next;
     }
+    if (!use_hist && a.hits) flush_counts();
     if constexpr (HIST) {
         if (a.hits && use_hist) {
             __syncthreads(); // every wave's histogram adds are done
