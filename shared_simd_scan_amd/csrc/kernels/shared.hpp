@@ -1052,19 +1052,62 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
     hits_finalize(a, P, lane);
 }
 
-// ---- shared scan, linear layout, P = 32 .. 1024 a power of two: lanes in memory order ---------------------------------
+// ---- shared scan, linear layout, P = 9 .. 1024: lanes in memory order ------------------------------------------------
 // The linear output (byte of 8-value group g and key k at g*P + k, src/simd_scan_shared_linear.cpp:57) of a tile is ONE
 // contiguous block of 512 rows x P bytes.  shared_wide_kernel gives every lane 8 consecutive rows, so a store instruction
 // writes 64 pieces of 16 bytes 8P bytes apart: every 128-byte line is written in 8 or more separate visits, and lines
 // that leave the L2 partly written cost a read-modify-write in ECC-protected HBM (the same effect made per-predicate
-// bitmaps at a non-line-multiple stride up to 2x slower).  Here the 64 lanes of a wave own 64 CONSECUTIVE 32-byte
-// pieces of the output: piece p of the tile = row p / Q, key-quarter p % Q (Q = P / 32 tables of 32 keys), so a wave step
-// writes 2 KiB contiguous with two back-to-back 16-byte stores per lane.  A lane fetches the c bytes of its row from
-// the tile's LDS image (lanes of one row read the same words: broadcast), shifts them into place with byte-granular
-// funnel shifts and decodes the 8 values at compile-time offsets; 8 lookups in ITS quarter's table and one 8 x 32 bit
-// transpose (group form) give the 32 bytes.  Hit counts: per-byte population counts of the 32 result bytes, summed in
-// packed byte counters per lane (a lane keeps its quarter: Q divides 64), flushed to the block's LDS counters per tile.
-// RP = rows per 32-byte piece: 1 for P >= 32 (a piece = 32 keys of one row), 2 for P = 16 (a piece = two whole rows).
+// bitmaps at a non-line-multiple stride up to 2x slower).  Here the lanes of a wave own CONSECUTIVE pieces of the
+// output: a row's P bytes are T = ceil(P/32) pieces of 32 bytes (the last one P - 32 (T-1) bytes), one per table of 32
+// keys; lane l of a step has table l mod Q, Q = T rounded up to a power of two (lanes whose table does not exist idle:
+// none when P is a power of two), and row l / Q -- so a wave step writes 64 / Q whole rows back to back, 2 KiB
+// contiguous when P is a multiple of 32.  A lane fetches the c bytes of its row from the tile's LDS image (lanes of one row
+// read the same words: broadcast), shifts them into place with byte-granular funnel shifts and decodes the 8 values at
+// compile-time offsets; 8 lookups in ITS table and one 8 x 32 bit transpose (group form) give the 32 bytes.  Pieces
+// start at any byte when P is not a multiple of 16: plain unaligned 16-byte stores (the hardware runs in unaligned-access
+// mode), a short last piece as 16 + 8 + 4 + 2 + 1 bytes.  Hit counts: per-byte population counts of the 32 result bytes,
+// summed in packed byte counters per lane (a lane keeps its table: Q divides 64), flushed to the block's LDS counters
+// every 31 steps; from P = 128 on (c <= 12) a histogram of the values instead.
+// RP = rows per 32-byte piece: 1 (a piece = up to 32 keys of one row), or 2 for P = 16 (a piece = two whole rows).
+struct __attribute__((packed, aligned(1))) Unaligned16 {
+    uint32_t a, b, c, d;
+};
+struct __attribute__((packed, aligned(1))) Unaligned8 {
+    uint32_t a, b;
+};
+struct __attribute__((packed, aligned(1))) Unaligned4 {
+    uint32_t a;
+};
+struct __attribute__((packed, aligned(1))) Unaligned2 {
+    uint16_t a;
+};
+// the first nbytes (1..31) of the 32 bytes in y[], to any address
+__device__ __forceinline__ void store_row_piece(uint8_t *p, const uint32_t (&y)[8], uint32_t nbytes)
+{
+    uint32_t c0 = y[0], c1 = y[1], c2 = y[2], c3 = y[3];
+    if (nbytes & 16u) {
+        *(Unaligned16 *)p = Unaligned16{c0, c1, c2, c3};
+        c0 = y[4], c1 = y[5], c2 = y[6], c3 = y[7];
+        p += 16;
+    }
+    if (nbytes & 8u) {
+        *(Unaligned8 *)p = Unaligned8{c0, c1};
+        c0 = c2, c1 = c3;
+        p += 8;
+    }
+    if (nbytes & 4u) {
+        *(Unaligned4 *)p = Unaligned4{c0};
+        c0 = c1;
+        p += 4;
+    }
+    if (nbytes & 2u) {
+        *(Unaligned2 *)p = Unaligned2{(uint16_t)c0};
+        c0 >>= 16;
+        p += 2;
+    }
+    if (nbytes & 1u) *p = (uint8_t)c0;
+}
+
 template <int C, int AUX_, int RP>
 __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a)
 {
@@ -1094,12 +1137,15 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
     const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
     uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
     const uint32_t P = a.nkeys;
-    const uint32_t Q = RP == 1 ? P / 32 : 1; // tables of 32 keys per row: 1, 2, 4, ... 32
-    const uint32_t qshift = 31 - __builtin_clz(Q);
+    const uint32_t T = RP == 1 ? (P + 31) / 32 : 1;                 // tables of 32 keys per row
+    const uint32_t qshift = T > 1 ? 32 - __builtin_clz(T - 1) : 0;  // Q = T rounded up to a power of two: 1, 2, 4, ... 32
+    const uint32_t Q = 1u << qshift;
+    const uint32_t last_bytes = RP == 1 ? P - 32 * (T - 1) : 32;    // bytes of a row's last piece, 1..32
+    const bool aligned16 = (P & 15u) == 0;                          // every piece starts on a 16-byte boundary
     const bool use_hist = HIST && P >= 128;
 
     if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
-    for (uint32_t i = threadIdx.x; i < Q * L::TABLE_DWORDS; i += kBlockThreads) lut[i] = 0;
+    for (uint32_t i = threadIdx.x; i < T * L::TABLE_DWORDS; i += kBlockThreads) lut[i] = 0;
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) {
         const uint32_t key = (uint32_t)a.keys_dev[k];
@@ -1115,12 +1161,19 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
     }
     __syncthreads();
 
-    // the lane's key-quarter is the same in every step (Q divides 64); its first row advances by 64 RP / Q per step
+    // the lane's table is the same in every step (Q divides 64); its first row advances by 64 RP / Q per step
     const uint32_t quarter = (uint32_t)lane & (Q - 1);
+    const bool has_table = quarter < T; // (Q > T: the lanes of the tables that do not exist sit the steps out)
     const uint32_t row_first = ((uint32_t)lane >> qshift) * RP;
     const uint32_t row_step = (64u >> qshift) * RP;
     const uint32_t nsteps = (uint32_t)ROWS * Q / (64 * RP);
-    const uint32_t *const table = lut + quarter * L::TABLE_DWORDS;
+    const uint32_t *const table = lut + (has_table ? quarter : 0u) * L::TABLE_DWORDS;
+    const uint32_t piece_bytes = quarter + 1 == T ? last_bytes : 32u;
+    // histogram hit counts: the T lanes of a row share its values -- value i belongs to the lane of table i mod T
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < 8 * RP; i++)
+        if ((uint32_t)i % T == quarter) mine |= 1u << i;
     // packed per-byte hit counters of the piece's 32 result bytes: at most 8 per step, so they are flushed to the block's
     // LDS counters every 31 steps -- counted ACROSS tiles (a tile is only 4 steps at P = 16, 8 at P = 32: flushing per
     // tile cost 32 LDS atomics per lane every 4 steps, a third of the kernel's time with hit counts)
@@ -1152,7 +1205,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
 #pragma unroll 1
         for (uint32_t s = 0; s < nsteps; s++) {
             const uint32_t row = row_first + s * row_step;
-            if (row < rows_here) { // (rows beyond the column: nothing is written)
+            if (row < rows_here && has_table) { // (rows beyond the column: nothing is written)
                 // the piece's RB bytes start at byte row * C of the tile: fetch the dwords around them, shift into place
                 const uint32_t byte0 = row * C;
                 const uint32_t *src = (const uint32_t *)(lds_wave + (byte0 & ~3u));
@@ -1187,15 +1240,27 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
                         y[2 * KB * h + 2 * b + 1] = hi;
                     }
                 }
-                u32x4 *dst = (u32x4 *)(out_tile + ((uint64_t)s * 64 + lane) * 32);
-                dst[0] = u32x4{y[0], y[1], y[2], y[3]};
-                // (RP = 2: the second row of the piece; it exists unless the column ends on the first)
-                if (RP == 1 || row + 1 < rows_here) dst[1] = u32x4{y[4], y[5], y[6], y[7]};
+                if constexpr (RP == 2) {
+                    u32x4 *dst = (u32x4 *)(out_tile + ((uint64_t)s * 64 + lane) * 32);
+                    dst[0] = u32x4{y[0], y[1], y[2], y[3]};
+                    // (the second row of the piece; it exists unless the column ends on the first)
+                    if (row + 1 < rows_here) dst[1] = u32x4{y[4], y[5], y[6], y[7]};
+                } else {
+                    uint8_t *dst = out_tile + (uint64_t)row * P + 32u * quarter;
+                    if (piece_bytes == 32 && aligned16) {
+                        ((u32x4 *)dst)[0] = u32x4{y[0], y[1], y[2], y[3]};
+                        ((u32x4 *)dst)[1] = u32x4{y[4], y[5], y[6], y[7]};
+                    } else if (piece_bytes == 32) {
+                        *(Unaligned16 *)dst = Unaligned16{y[0], y[1], y[2], y[3]};
+                        *(Unaligned16 *)(dst + 16) = Unaligned16{y[4], y[5], y[6], y[7]};
+                    } else {
+                        store_row_piece(dst, y, piece_bytes);
+                    }
+                }
                 if (HIST && use_hist) {
-                    // the Q lanes of a row share the counting of its 8 values: value i belongs to the lane whose table index
-                    // is i mod Q (Q >= 8: one value per lane, picked by a select chain -- one atomic instruction per step)
+                    // (T >= 8: one value per lane, picked by a select chain -- one atomic instruction per step)
                     if (a.hits) {
-                        if (Q >= 8) {
+                        if (T >= 8) {
                             uint32_t xi = x[0];
 #pragma unroll
                             for (int i = 1; i < 8; i++) xi = quarter == (uint32_t)i ? x[i] : xi;
@@ -1204,7 +1269,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
                         } else {
 #pragma unroll
                             for (int i = 0; i < 8 * RP; i++)
-                                if (((uint32_t)i & (Q - 1)) == quarter && (uint32_t)i < nvalid)
+                                if (((mine >> i) & 1u) && (uint32_t)i < nvalid)
                                     __hip_atomic_fetch_add(&hist[x[i]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }

@@ -172,10 +172,13 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         // c = 9): 1e8 rows (100 MB of bitmaps) 0.0540 -> 0.0525 ms, 5e8 0.220 -> 0.214, 1e9 0.409 -> 0.372; c = 17: -1..-4 %.
         // Unlike the single bitmap of launch_scan, these outputs gain nothing from staying in the Infinity Cache.
         const bool nt_stores = r.scan_nt_stores < 0 ? (r.scan.n / 8) * P > (64ull << 20) : r.scan_nt_stores != 0;
+        // linear rows of 9 .. 1024 keys: lanes in memory order (shared_linear_kernel).  It needs two blocks per CU to hide its
+        // lookups: tables too big for that -- P = 1024 at c <= 10 -- stay on the per-group kernel unless hit counts are
+        // wanted (2.5e8 x 9 bit, P = 1024: 13.5 against 10.2 ms without, 15.6 against 17.8 with).  (flags bit 1: the older kernels, A/B)
+        const bool lin_rows = linear && P > 8 && lut_fits<C, VPL>(P) && !(r.scan.flags & 2u) &&
+                              (2 * ((size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES + lut_static_lds<C, VPL>()) <= 160 * 1024 || r.scan.hits);
         if (r.choice_out) { // introspection (mi355_shared_scan_kernel): which kernel family would run, nothing is launched
-            const bool lin_pow2 = linear && P >= 16 && (P & (P - 1)) == 0 && lut_fits<C, VPL>(P) && !(r.scan.flags & 2u) &&
-                                  (2 * ((size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES + lut_static_lds<C, VPL>()) <= 160 * 1024 || r.scan.hits);
-            *r.choice_out = P <= 8 ? 0 : lin_pow2 ? 4 : (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) ? 1 : lut_fits<C, VPL>(P) ? 2 : 3;
+            *r.choice_out = P <= 8 ? 0 : lin_rows ? 4 : (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) ? 1 : lut_fits<C, VPL>(P) ? 2 : 3;
             break;
         }
         if (P <= 8) { // LDS lookup table, one pass, deferred stores
@@ -188,8 +191,7 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 }
             }
             launch_lut8<C, 64>(r, P, linear);
-        } else if (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P) &&
-                   !(P >= 16 && (P & (P - 1)) == 0 && lut_fits<C, VPL>(P) && !(r.scan.flags & 2u))) {
+        } else if (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P) && !lin_rows) {
             // linear rows of fewer than ~200 keys without hit counts: byte-entry tables, 16 output bytes per round
             // (measured, tools/sweep_p.py, 2.5e8 x 9 bit: P = 16 / 32 / 64 / 128 0.21 / 0.43 / 0.72 / 1.45 ms against
             // 0.41 / 0.58 / 0.91 / 1.50 for the dword-entry kernel, which wins from P = 256: 2.80 against 3.16 ms)
@@ -205,11 +207,7 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
             allow_dynamic_lds<shared_wide_kernel<C, 18, VPL, 0>>(max_dyn, r.device);
             const int want = r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : 2;
             const dim3 grid(grid_for(ntiles, want, r.num_cus));
-            // (it needs two blocks per CU to hide its lookups: tables too big for that -- P = 1024 at c <= 10 -- stay on the
-            // per-group kernel unless hit counts are wanted: 2.5e8 x 9 bit, P = 1024: 13.5 against 10.2 ms without, 15.6 against 17.8 with)
-            const bool lin_two_blocks = 2 * (dyn + lut_static_lds<C, VPL>()) <= 160 * 1024 || r.scan.hits != nullptr;
-            if (linear && P >= 16 && (P & (P - 1)) == 0 && lin_two_blocks && !(r.scan.flags & 2u)) {
-                // linear rows of 16 .. 1024 keys, a power of two: lanes in memory order (2 KiB contiguous per wave step)
+            if (lin_rows) {
                 allow_dynamic_lds<shared_linear_kernel<C, 2, 1>>(max_dyn, r.device);
                 allow_dynamic_lds<shared_linear_kernel<C, 2, 2>>(max_dyn, r.device);
                 const dim3 lgrid(grid_for(ntiles, r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : 4, r.num_cus));

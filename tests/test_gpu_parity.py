@@ -406,6 +406,40 @@ def test_linear_layout_lanes_in_memory_order(O, eng, L, c, P):
                 assert np.array_equal(hits.cpu().numpy(), np.array([int(((v == k) & (k < (1 << c))).sum()) for k in keys]))
 
 
+@pytest.mark.parametrize("c", [3, 9, 12, 17, 32])
+@pytest.mark.parametrize("P", [9, 10, 11, 13, 15, 17, 23, 31, 33, 47, 63, 65, 95, 96, 97, 100, 127, 129, 160, 255, 257, 500, 777, 1023])
+def test_linear_layout_any_key_count(O, eng, L, c, P):
+    """shared_linear_kernel with key counts that are not powers of two (the reference's own sweep is P = 1 .. 512 in
+    steps of one, scripts/prepare_shared_scan_results.py:28-31): rows of P bytes start at any byte, the last piece of a row
+    is 1 .. 31 bytes, lanes of tables that do not exist idle.  Whole output compared with numpy, guard bytes behind the
+    output untouched, columns ending inside a row / on a row boundary / on a tile boundary / inside the first piece."""
+    import torch
+
+    choice = L.mi355_shared_scan_kernel(eng._ctx, c, P, 1, 1)
+    if choice != b"shared_linear_kernel":
+        pytest.skip(f"tables of {P} keys at c={c} do not fit LDS: {choice}")
+    rng = np.random.default_rng(c * 10000 + P)
+    for n in (4096 * 3 + 77, 4096 * 2 + 16, 4096 * 2, 5):
+        vals, col = make_column(O, eng, n, c, 7100 + c + P + n)
+        v = vals.astype(np.int64)
+        keys = [int(vals[int(i)]) for i in rng.integers(0, n, size=P)]
+        keys[3] = keys[1]
+        if c < 31:
+            keys[5] = (1 << c) + 2
+        keys[P - 1] = int(vals[0])  # the last key of the short piece matches something
+        keys32 = [k if k < 2 ** 31 else k - 2 ** 32 for k in keys]
+        nb = (n + 7) // 8
+        expect = np.stack([np_bitmap((v == k) & (k < (1 << c))) for k in keys]).T.reshape(-1)  # [nb, P] row-major
+        for count in (True, False):
+            buf = torch.full((nb * P + 256,), 0xEE, dtype=torch.uint8, device="cuda")
+            out, hits = eng.shared_scan(keys32, col, layout="linear", out=buf[:nb * P], hits=None if count else False)
+            got = buf.cpu().numpy()
+            assert np.array_equal(got[:nb * P], expect), (c, P, n, count)
+            assert (got[nb * P:] == 0xEE).all(), (c, P, n, count)
+            if count:
+                assert np.array_equal(hits.cpu().numpy(), np.array([int(((v == k) & (k < (1 << c))).sum()) for k in keys]))
+
+
 def test_out_of_range_keys_never_match(O, eng):
     """SURVEY 8c hazard 5: keys 515, 1027, 65539, -1 on a 9-bit column -> no hits, zero bitmap."""
     import torch
