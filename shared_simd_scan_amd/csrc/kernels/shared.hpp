@@ -868,7 +868,9 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide_kernel(ScanArgs a)
 // 4x4 byte transposes so that register R[b][i] holds key-byte b of values i, 8+i, 16+i, 24+i, and each key-byte takes
 // the register-wise 8x8 bit transpose of the one-pass kernel (transpose_bits_8regs: 72 VOP2 operations for 32 values x
 // 8 keys): afterwards R[b][q] IS the bitmap word of key 8b + q -- 0.34 operations per result, no gather.
-template <int C, int AUX_, int VPL>
+// REGCNT: hit counts of a single 32-key round (P <= 32) in 32 registers of the lane (see below); its own instantiation
+// because the registers would cost the other paths a resident wave (c = 11, 12: 248 -> 256 + spills to AGPRs).
+template <int C, int AUX_, int VPL, bool REGCNT = false>
 __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
 {
     using G = ScanGeom<C, VPL>;
@@ -899,11 +901,11 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
     uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
     const uint32_t P = a.nkeys;
     const uint32_t npass32 = (P + 31) / 32;
-    const bool reg_counts = npass32 == 1 && !(a.flags & 8u); // (flags bit 3: the per-tile wave reductions, for A/B)
+    constexpr bool reg_counts = REGCNT; // (the launcher picks it for P <= 32 with hit counts)
     const bool use_hist = HIST && P >= 64;
-    uint32_t acc[4][8];
+    uint32_t acc[REGCNT ? 4 : 1][8];
 #pragma unroll
-    for (int b = 0; b < 4; b++)
+    for (int b = 0; b < (REGCNT ? 4 : 1); b++)
 #pragma unroll
         for (int q = 0; q < 8; q++) acc[b][q] = 0;
 
@@ -983,7 +985,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
             for (int b = 0; b < 4; b++) {
                 const uint32_t pass = p32 * 4 + b;
                 if (pass * 8 < P) {
-                    if (a.hits && reg_counts) {
+                    if constexpr (reg_counts) {
 #pragma unroll
                         for (int q = 0; q < 8; q++)
 #pragma unroll
@@ -1022,7 +1024,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
         }
         tile = next;
     }
-    if (a.hits && reg_counts) {
+    if constexpr (reg_counts) {
         // a lane's count is below 2^32 (it sees at most n / 64 values); the wave's sum need not be: reduce in 64 bits
 #pragma unroll
         for (int b = 0; b < 4; b++)

@@ -216,12 +216,25 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 else
                     hipLaunchKernelGGL((shared_linear_kernel<C, 2, 1>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);
             } else if (!linear && !(r.scan.flags & 2u)) { // (flags bit 1: the per-group kernel, for A/B)
-                allow_dynamic_lds<shared_wide2_kernel<C, 2, VPL>>(max_dyn, r.device);
-                allow_dynamic_lds<shared_wide2_kernel<C, 18, VPL>>(max_dyn, r.device);
-                if (nt_stores)
-                    hipLaunchKernelGGL((shared_wide2_kernel<C, 18, VPL>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
-                else
-                    hipLaunchKernelGGL((shared_wide2_kernel<C, 2, VPL>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+                // one 32-key round with hit counts: the counts stay in registers (2.5e8 x 9 bit, same box: P = 16 0.200 -> 0.158 ms,
+                // P = 32 0.298 -> 0.249); single-table widths only -- the digit tables of c > 10 leave no registers for it
+                // (flags bit 3: the per-tile wave reductions, for A/B)
+                auto go = [&](auto regcnt) {
+                    constexpr bool R = decltype(regcnt)::value;
+                    allow_dynamic_lds<shared_wide2_kernel<C, 2, VPL, R>>(max_dyn, r.device);
+                    allow_dynamic_lds<shared_wide2_kernel<C, 18, VPL, R>>(max_dyn, r.device);
+                    if (nt_stores)
+                        hipLaunchKernelGGL((shared_wide2_kernel<C, 18, VPL, R>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+                    else
+                        hipLaunchKernelGGL((shared_wide2_kernel<C, 2, VPL, R>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+                };
+                if constexpr (WideLutGeom<C>::SINGLE) {
+                    if (P <= 32 && r.scan.hits && !(r.scan.flags & 8u)) {
+                        go(std::true_type{});
+                        break;
+                    }
+                }
+                go(std::false_type{});
             } else if (linear)
                 hipLaunchKernelGGL((shared_wide_kernel<C, 2, VPL, 1>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
             else if (nt_stores)
