@@ -554,6 +554,82 @@ def test_more_than_2_pow_32_rows(O, eng, c):
     torch.cuda.empty_cache()
 
 
+def test_more_than_2_pow_32_rows_round2_kernels(O, eng):
+    """the kernels added after the first >2^32-row test, on the same column shape (2^32 + 3*8192 + 77 rows of v[i] = i % 7,
+    9 bit): count-only and fused-mask scans, two columns in one launch, IN-list, the fused selection (row ids > 2^32),
+    shared scans of 8 / 12 / 16 / 40 keys in both layouts (LUT, register-count, lanes-in-memory-order kernels) and
+    decompress -- exact hit counts from the generator's period, oracle windows across row 2^32 and over the ragged end"""
+    import torch
+
+    c = 9
+    n = (1 << 32) + 3 * 8192 + 77
+    col = eng.generate("mod", n, c, 7)
+    per_key = [(n - 1 - k) // 7 + 1 for k in range(7)]
+    nb = (n + 7) // 8
+    windows = [((1 << 32) - 8192 * 2, 8192 * 4 + 96), (n - 77 - 8192, 77 + 8192)]
+
+    def window_packed(a, ln):
+        return col.data[a * c // 8: a * c // 8 + (ln * c + 7) // 8].cpu().numpy()
+
+    # count-only, fused masks, two columns, IN-list
+    bm5, h5 = eng.scan(5, col)
+    assert int(h5.item()) == per_key[5]
+    _, hc = eng.scan_combine("==", 5, col, count_only=True)
+    assert int(hc.item()) == per_key[5]
+    bor, hor = eng.scan_combine("==", 2, col, mask=bm5, mask_op="or")
+    assert int(hor.item()) == per_key[5] + per_key[2]
+    bin_, hin = eng.scan_in([2, 5, 300], col)
+    assert int(hin.item()) == per_key[5] + per_key[2] and torch.equal(bin_, bor)
+    b2, h2 = eng.scan2(col, ">=", 2, col, "<=", 4, combine="and")
+    assert int(h2.item()) == per_key[2] + per_key[3] + per_key[4]
+    for a, ln in windows:
+        pk = window_packed(a, ln)
+        obm, _ = O.scan_range(pk, ln, c, 2, 4)
+        assert np.array_equal(b2[a // 8: a // 8 + (ln + 7) // 8].cpu().numpy(), obm)
+        o2, _ = O.scan_eq(pk, ln, c, 2)
+        o5, _ = O.scan_eq(pk, ln, c, 5)
+        assert np.array_equal(bor[a // 8: a // 8 + (ln + 7) // 8].cpu().numpy(), o2 | o5)
+    del bor, bin_, b2
+
+    # fused selection: every id, the tail against numpy (row ids above 2^32)
+    ids, cnt = eng.scan_select("==", 5, col, capacity=per_key[5])
+    assert int(cnt.item()) == per_key[5]
+    step = 1 << 28
+    for j0 in range(0, per_key[5], step):
+        j1 = min(per_key[5], j0 + step)
+        assert torch.equal(ids[j0:j1], torch.arange(j0, j1, dtype=torch.int64, device="cuda") * 7 + 5), j0
+    assert int(ids[per_key[5] - 1].item()) > (1 << 32)
+    del ids, bm5
+    torch.cuda.empty_cache()
+
+    # shared scans: per-key counts from the period, windows against the oracle
+    for P in (8, 12, 16, 40):
+        keys = [(3 * k + 1) % 11 for k in range(P)]  # values 0..10: 7..10 match nothing, duplicates from k = 11 on
+        want = [per_key[k] if k < 7 else 0 for k in keys]
+        for layout in ("per_predicate", "linear"):
+            out, hits = eng.shared_scan(keys, col, layout=layout)
+            assert hits.cpu().tolist() == want, (P, layout)
+            for a, ln in windows:
+                oout, _ = O.shared_scan_eq(window_packed(a, ln), ln, c, keys, layout)
+                wb = (ln + 7) // 8
+                if layout == "per_predicate":
+                    assert np.array_equal(out[:, a // 8: a // 8 + wb].cpu().numpy(), oout), (P, layout, a)
+                else:
+                    assert np.array_equal(out[(a // 8) * P: (a // 8 + wb) * P].cpu().numpy(), oout.reshape(-1)), (P, layout, a)
+            assert nb * P <= out.numel()
+            del out
+            torch.cuda.empty_cache()
+
+    # decompress: all n values against the generator, on the device in slices
+    dec = eng.decompress(col)
+    step = 1 << 29
+    for i0 in range(0, n, step):
+        i1 = min(n, i0 + step)
+        assert torch.equal(dec[i0:i1], (torch.arange(i0, i1, dtype=torch.int64, device="cuda") % 7).to(torch.int32)), i0
+    del dec, col
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("c,n", [(5, 100_000_000), (9, 100_000_000), (17, 100_000_000),
                                  (5, 1_000_000_000), (7, 1_000_000_000), (9, 1_000_000_000), (12, 1_000_000_000),
                                  (17, 1_000_000_000), (21, 1_000_000_000)])
