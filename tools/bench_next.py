@@ -77,7 +77,7 @@ def main():
         eng.scan_combine(">=", (1 << c) // 8, col2, mask=b1, mask_op="and", bitmap=out, hits=h1)
 
     t2 = timed(two_launches)
-    report("col1 < a AND col2 >= b: scan + fused-mask scan", t2, 2 * pk + 3 * nb, "2 launches, 125 MB bitmap written + read in between")
+    report("col1 < a AND col2 >= b: scan + fused-mask scan", t2, 2 * pk + 3 * nb, f"2 launches, {nb / 1e6:.0f} MB bitmap written + read in between")
     t1 = timed(lambda: eng.scan2(col, "<", (1 << c) // 4, col2, ">=", (1 << c) // 8, combine="and", bitmap=out, hits=h1))
     report("col1 < a AND col2 >= b: mi355_scan2_dev", t1, 2 * pk + nb, f"1 launch, no intermediate bitmap: {t2 / t1:.2f}x")
     report("col1 < a AND col2 >= b: scan2, count only", timed(lambda: eng.scan2(col, "<", (1 << c) // 4, col2, ">=", (1 << c) // 8, hits=h1, count_only=True)), 2 * pk)
