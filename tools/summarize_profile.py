@@ -58,6 +58,19 @@ def main():
         out["hbm_bytes_per_launch"] = rd + wr
     if "GRBM_GUI_ACTIVE" in mean and stats:
         out["effective_clock_ghz"] = mean["GRBM_GUI_ACTIVE"] / 8 / float(stats["AverageNs"])
+    # the L2's memory-side interface (TCC -> Infinity Fabric / HBM): Little's law on the request-level counters
+    mem = {}
+    if mean.get("TCC_EA0_RDREQ_sum") and "TCC_EA0_RDREQ_LEVEL_sum" in mean:
+        mem["read_latency_tcc_cycles"] = mean["TCC_EA0_RDREQ_LEVEL_sum"] / mean["TCC_EA0_RDREQ_sum"]
+        if mean.get("TCC_CYCLE_sum"):
+            mem["reads_in_flight_per_channel"] = mean["TCC_EA0_RDREQ_LEVEL_sum"] / mean["TCC_CYCLE_sum"]
+            mem["read_dram_credit_stall_frac"] = mean.get("TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum", 0.0) / mean["TCC_CYCLE_sum"]
+    if mean.get("TCC_EA0_WRREQ_sum") and "TCC_EA0_WRREQ_LEVEL_sum" in mean:
+        mem["write_latency_tcc_cycles"] = mean["TCC_EA0_WRREQ_LEVEL_sum"] / mean["TCC_EA0_WRREQ_sum"]
+        mem["write_stall_per_request"] = mean.get("TCC_EA0_WRREQ_STALL_sum", 0.0) / mean["TCC_EA0_WRREQ_sum"]
+        mem["write_dram_credit_stall_per_request"] = mean.get("TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum", 0.0) / mean["TCC_EA0_WRREQ_sum"]
+    if mem:
+        out["memory_side"] = mem
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     base = os.path.join(ROOT, "profiles", f"{tag}_{workload}_{rows:.0e}x{bits}".replace("+", ""))
     json.dump(out, open(base + ".json", "w"), indent=1)
@@ -76,6 +89,10 @@ def main():
             f.write(f"- read  = FETCH_SIZE x 1024 x 2 = {out['hbm_read_bytes_per_launch']:.4e} B\n")
             f.write(f"- write = WRITE_SIZE x 1024     = {out['hbm_write_bytes_per_launch']:.4e} B\n")
             f.write(f"- total = {out['hbm_bytes_per_launch']:.4e} B\n")
+        if mem:
+            f.write("\n## L2 <-> memory interface (TCC_EA0_*; level / requests = average time a request is outstanding)\n\n")
+            for k, v in mem.items():
+                f.write(f"- {k} = {v:.3f}\n")
         if "effective_clock_ghz" in out:
             f.write(f"\neffective clock = GRBM_GUI_ACTIVE / 8 / kernel time = {out['effective_clock_ghz']:.2f} GHz\n")
     if "hbm_bytes_per_launch" in out:
