@@ -29,7 +29,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-tune", action="store_true", help="skip the engine's load-time tuning of blocks per CU (static defaults)")
+    ap.add_argument("--tune", action="store_true", help="let the engine measure 1 / 2 / 4 resident blocks per CU on this device first "
+                    "(mi355_tune_dev, untimed setup); off by default so that every launch of the kernel in a rocprofv3 trace of this "
+                    "command is a launch of the timed configuration")
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="values per GPU")
     ap.add_argument("--bits", type=int, default=9)
     ap.add_argument("--column", choices=["mod5", "random"], default="mod5",
@@ -254,10 +256,10 @@ def main():
         algo_bytes = n * c / 8 + 4 * n
         kname = kernel_name("decompress", c)
 
-    # load-time tuning (mi355_tune_dev): what a service does once after loading a column -- the engine measures 1 / 2 / 4
-    # resident blocks per CU on THIS device and keeps the fastest; setup, outside the warm-up and the timed region
+    # --tune: load-time tuning (mi355_tune_dev), what a service does once after loading a column -- the engine measures
+    # 1 / 2 / 4 resident blocks per CU on THIS device and keeps the fastest; setup, outside the warm-up and the timed region
     tuned = {}
-    if not args.no_tune and args.workload != "shared_scan":
+    if args.tune and args.workload != "shared_scan":
         tuned = eng.tune(col, "decompress" if args.workload == "decompress" else "scan")
 
     def sync_all():

@@ -15,9 +15,9 @@ for c in (1, 2, 5, 9, 12, 16, 21, 32):
     del col; torch.cuda.empty_cache()
 PY
 for i in 1 2 3; do
-  python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-tune >> $out/bench_notune.jsonl 2>>$out/err.log
-  python bench.py --steps 200 --warmup 20 --no-cpu-baseline >> $out/bench_tune.jsonl 2>>$out/err.log
+  python bench.py --steps 200 --warmup 20 --no-cpu-baseline >> $out/bench_notune.jsonl 2>>$out/err.log
+  python bench.py --steps 200 --warmup 20 --no-cpu-baseline --tune >> $out/bench_tune.jsonl 2>>$out/err.log
 done
-python bench.py --workload decompress --steps 50 --warmup 5 --no-cpu-baseline --no-tune >> $out/bench_dec.jsonl 2>>$out/err.log
 python bench.py --workload decompress --steps 50 --warmup 5 --no-cpu-baseline >> $out/bench_dec.jsonl 2>>$out/err.log
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_driver_shape.json 2>>$out/err.log
+python bench.py --workload decompress --steps 50 --warmup 5 --no-cpu-baseline --tune >> $out/bench_dec.jsonl 2>>$out/err.log
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --tune > $out/bench_driver_shape.json 2>>$out/err.log
