@@ -292,6 +292,34 @@ template <int VPL> __device__ __forceinline__ void lut_gather_keys(const uint32_
     }
 }
 
+struct __attribute__((packed, aligned(1))) Unaligned16 {
+    uint32_t a, b, c, d;
+};
+// Linear layout, P = 3, 5, 6, 7 keys (one pass): the lane's GROUPS rows of P bytes are GROUPS*P CONTIGUOUS output bytes
+// (8-byte aligned), the wave's tile 64 x that.  Y[g] = (lo, hi) holds row g with key q in byte q: the rows are packed
+// back to back in registers -- every shift and byte select is a compile-time constant once P is one -- and leave as
+// 16 / 8-byte stores.  (Byte stores straight from Y, the first version, ran at 0.6-2.0 TB/s: 8 P store instructions per lane
+// and tile; 2.5e8 x 9 bit, P = 7: 0.875 ms.)
+template <int P, int GROUPS, int NRES> __device__ __forceinline__ void store_linear_rows_packed(uint8_t *dst, const uint32_t (&res)[NRES])
+{
+    constexpr int NDW = GROUPS * P / 4; // GROUPS is a multiple of 8
+    uint32_t d[NDW];
+#pragma unroll
+    for (int i = 0; i < NDW; i++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int b = 4 * i + k, g = b / P, q = b % P;
+            v |= ((res[2 * g + (q >> 2)] >> (8 * (q & 3))) & 0xffu) << (8 * k);
+        }
+        d[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i + 4 <= NDW; i += 4) *(Unaligned16 *)(dst + 4 * i) = Unaligned16{d[i], d[i + 1], d[i + 2], d[i + 3]};
+    if constexpr (NDW % 4 >= 2) store8_unaligned(dst + 4 * (NDW & ~3), d[NDW & ~3], d[(NDW & ~3) + 1]);
+    static_assert(NDW % 2 == 0, "GROUPS * P is a multiple of 8 bytes");
+}
+
 // LAYOUT 0: per-predicate bitmaps at out + k*out_stride; 1: linear (byte of 8-value group g and key k at
 // g*P + k, src/simd_scan_shared_linear.cpp:57).  MULTI false: P <= 8, one pass, stores deferred by one tile
 // (as in scan_kernel); true: ceil(P/8) passes per tile, stored pass by pass.
@@ -394,6 +422,14 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
                                __builtin_amdgcn_perm(res[2 * g + 14], res[2 * g + 12], 0x05040100u)};
                     dst[g / 8] = v;
                 }
+            } else if (!MULTI && P == 3) {
+                store_linear_rows_packed<3, GROUPS, NRES>(a.out + g0 * 3, res);
+            } else if (!MULTI && P == 5) {
+                store_linear_rows_packed<5, GROUPS, NRES>(a.out + g0 * 5, res);
+            } else if (!MULTI && P == 6) {
+                store_linear_rows_packed<6, GROUPS, NRES>(a.out + g0 * 6, res);
+            } else if (!MULTI && P == 7) {
+                store_linear_rows_packed<7, GROUPS, NRES>(a.out + g0 * 7, res);
             } else {
                 const uint32_t nk = (P - pass * 8) < 8 ? (P - pass * 8) : 8;
 #pragma unroll
@@ -1071,9 +1107,6 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
 // summed in packed byte counters per lane (a lane keeps its table: Q divides 64), flushed to the block's LDS counters
 // every 31 steps; from P = 128 on (c <= 12) a histogram of the values instead.
 // RP = rows per 32-byte piece: 1 (a piece = up to 32 keys of one row), or 2 for P = 16 (a piece = two whole rows).
-struct __attribute__((packed, aligned(1))) Unaligned16 {
-    uint32_t a, b, c, d;
-};
 struct __attribute__((packed, aligned(1))) Unaligned8 {
     uint32_t a, b;
 };

@@ -231,7 +231,7 @@ def test_ragged_sizes(O, eng, n, c):
     assert np.array_equal(bm0.cpu().numpy(), obm0) and int(hits0.item()) == oh0 == int((vals == 0).sum())
 
 
-@pytest.mark.parametrize("P", [1, 2, 3, 5, 8, 9, 16, 37, 64, 65, 128, 300, 1024])
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 37, 64, 65, 128, 300, 1024])
 @pytest.mark.parametrize("layout", ["per_predicate", "linear"])
 def test_shared_scan_predicate_counts(O, eng, P, layout):
     n, c = 2 * 8192 + 77, 9
@@ -438,6 +438,39 @@ def test_linear_layout_any_key_count(O, eng, L, c, P):
             assert (got[nb * P:] == 0xEE).all(), (c, P, n, count)
             if count:
                 assert np.array_equal(hits.cpu().numpy(), np.array([int(((v == k) & (k < (1 << c))).sum()) for k in keys]))
+
+
+@pytest.mark.parametrize("c", [2, 7, 9, 12, 17, 32])
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("vpl", [0, 128])
+def test_linear_layout_up_to_8_keys(O, eng, c, P, vpl):
+    """linear rows of 1 .. 8 bytes (one-pass LUT kernel; P = 3, 5, 6, 7 pack the lane's rows back to back in registers):
+    whole output against numpy, guard bytes behind it untouched, ragged columns, both tile geometries where they exist"""
+    import torch
+
+    if vpl == 128 and c > 12:
+        pytest.skip("128 values per lane exist for c <= 12")
+    rng = np.random.default_rng(c * 100 + P)
+    try:
+        eng.set_option("shared_vpl", vpl)
+        for n in (8192 * 5 + 77, 8192 * 2 + 16, 8192 * 2, 5):
+            vals, col = make_column(O, eng, n, c, 8100 + c + P + n)
+            v = vals.astype(np.int64)
+            keys = [int(vals[int(i)]) for i in rng.integers(0, n, size=P)]
+            if P > 2 and c < 31:
+                keys[1] = (1 << c) + 2  # out of range: a zero byte in every row
+            nb = (n + 7) // 8
+            expect = np.stack([np_bitmap((v == k) & (k < (1 << c))) for k in keys]).T.reshape(-1)  # [nb, P] row-major
+            for count in (True, False):
+                buf = torch.full((nb * P + 256,), 0xEE, dtype=torch.uint8, device="cuda")
+                out, hits = eng.shared_scan(keys, col, layout="linear", out=buf[:nb * P], hits=None if count else False)
+                got = buf.cpu().numpy()
+                assert np.array_equal(got[:nb * P], expect), (c, P, n, count, vpl)
+                assert (got[nb * P:] == 0xEE).all(), (c, P, n, count, vpl)
+                if count:
+                    assert np.array_equal(hits.cpu().numpy(), np.array([int(((v == k) & (k < (1 << c))).sum()) for k in keys]))
+    finally:
+        eng.set_option("shared_vpl", 0)
 
 
 def test_out_of_range_keys_never_match(O, eng):
