@@ -860,43 +860,6 @@ def test_one_tile_per_burst_option_agrees(O, eng, c):
     assert np.array_equal(r4.cpu().numpy(), orb) and np.array_equal(r1.cpu().numpy(), orb) and int(hr4.item()) == orh == int(hr1.item())
 
 
-@pytest.mark.parametrize("c", [2, 9, 21])
-def test_online_blocks_per_cu_choice_never_changes_results(O, eng, c):
-    """columns of >= 5e7 rows take part in the online choice of blocks per CU (ctx.hpp mi355_tuner): the first launches
-    alternate between 1 / 2 / 4 blocks per CU, then one is kept.  Every launch of the tuning phase and after it gives the
-    bytes of the static-default launch, for the scans (bitmap, count-only, fused mask) and for decompress."""
-    import torch
-
-    n = 50_000_000 + 12_345
-    col = eng.generate("splitmix", n, c, 600 + c)
-    key = 1
-    try:
-        eng.set_option("autotune", 0)
-        bm0, h0 = eng.scan(key, col)
-        r0, hr0 = eng.scan_range(1, (1 << c) // 2, col)
-        m0, hm0 = eng.scan_combine("==", key, col, mask=r0, mask_op="or")
-        d0 = eng.decompress(col)
-        eng.set_option("autotune", 2)  # forget anything learnt, tuning on
-        bm, r, m = eng.alloc_bitmap(n), eng.alloc_bitmap(n), eng.alloc_bitmap(n)
-        d = torch.empty_like(d0)
-        hits = torch.zeros(4, dtype=torch.int64, device="cuda")
-        for it in range(24):  # 3 candidates x 5 samples, then settled launches
-            eng.scan(key, col, bitmap=bm, hits=hits[0:1])
-            eng.scan_range(1, (1 << c) // 2, col, bitmap=r, hits=hits[1:2])
-            eng.scan_combine("==", key, col, mask=r0, mask_op="or", bitmap=m, hits=hits[2:3])
-            eng.scan_combine("==", key, col, hits=hits[3:4], count_only=True)
-            eng.decompress(col, out=d)
-            if it % 4 == 3 or it < 4:
-                assert torch.equal(bm, bm0) and torch.equal(r, r0) and torch.equal(m, m0) and torch.equal(d, d0), it
-                assert hits.tolist() == [int(h0.item()), int(hr0.item()), int(hm0.item()), int(h0.item())], it
-                bm.zero_(), r.zero_(), m.zero_(), d.zero_(), hits.zero_()
-    finally:
-        eng.set_option("autotune", 1)
-    # pinned against the oracle once (the rest of the suite covers the kernels themselves)
-    obm, ohits = O.scan_eq(col.data.cpu().numpy(), n, c, key)
-    assert np.array_equal(bm0.cpu().numpy(), obm) and int(h0.item()) == ohits
-
-
 @pytest.mark.parametrize("c", [1, 9, 21, 32])
 def test_load_time_tuning_never_changes_results(O, c):
     """mi355_tune_dev measures 1 / 2 / 4 blocks per CU on a resident column of >= 5e7 rows and keeps the fastest per
