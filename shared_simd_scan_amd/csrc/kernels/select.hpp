@@ -106,24 +106,32 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
 
     bool gave_up = false;
 
-    // hits in all chunks before q (decoupled look-back), then publishes q's inclusive prefix
-    auto resolve = [&](uint64_t q, unsigned long long q_hits) -> unsigned long long {
+    // one poll = kSelectWindow loads of 64 CONSECUTIVE state words each (512 B, four lines per instruction; a lane
+    // reading its own run of 16 words would touch 1024 lines per poll), all issued before the first is used: group k,
+    // lane l looks at chunk pos - 64 k - l
+    auto poll_issue = [&](int64_t pos, unsigned long long (&s)[kSelectWindow]) {
+#pragma unroll
+        for (int k = 0; k < kSelectWindow; k++) {
+            const int64_t i = pos - 64 * k - lane;
+            // chunks before the column: "prefix of nothing" = inclusive 0
+            s[k] = i >= 0 ? __hip_atomic_load(state + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+        }
+    };
+
+    // hits in all chunks before q (decoupled look-back), then publishes q's inclusive prefix.  The FIRST poll's loads are
+    // issued by the caller (poll_issue(q - 1, s)), who puts work that does not need the answer between issue and call.
+    auto resolve = [&](uint64_t q, unsigned long long q_hits, unsigned long long (&s)[kSelectWindow]) -> unsigned long long {
         if (q == 0) return 0ull; // chunk 0 published its inclusive prefix right away
         unsigned long long before = 0;
-        int64_t pos = (int64_t)q - 1; // nearest chunk of the poll; group k, lane l looks at chunk pos - 64 k - l
+        int64_t pos = (int64_t)q - 1; // nearest chunk of the poll
         uint32_t spins = 0;
         bool done = false;
         while (!done) {
-            // one poll = kSelectWindow loads of 64 CONSECUTIVE state words each (512 B, four lines per instruction; a
-            // lane reading its own run of 16 words would touch 1024 lines per poll), all issued before the first is used
-            unsigned long long s[kSelectWindow];
-#pragma unroll
-            for (int k = 0; k < kSelectWindow; k++) {
-                const int64_t i = pos - 64 * k - lane;
-                // chunks before the column: "prefix of nothing" = inclusive 0
-                s[k] = i >= 0 ? __hip_atomic_load(state + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
-            }
-            unsigned long long acc = 0;
+            // aggregates (status 1: a chunk's own count, < 2^17) are summed per lane in 32 bits and over the wave by DPP; the
+            // one inclusive prefix that ends the walk (status 2, up to n) is read from its lane -- a 64-bit __shfl_xor
+            // butterfly here was twelve dependent ds_bpermute round trips per chunk
+            uint32_t acc = 0;
+            unsigned long long prefix = 0;
             bool retry = false;
 #pragma unroll
             for (int k = 0; k < kSelectWindow; k++) {
@@ -139,14 +147,17 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
                         retry = true; // what was summed so far stays valid: resume at this group
                         pos -= 64 * k;
                     } else {
-                        if (lane <= stop) acc += s[k] & kSelectValueMask;
-                        done = stop < 64;
+                        if (lane < stop) acc += (uint32_t)s[k];
+                        if (stop < 64) {
+                            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)s[k], stop);
+                            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(s[k] >> 32), stop);
+                            prefix = (((unsigned long long)hi << 32) | lo) & kSelectValueMask;
+                            done = true;
+                        }
                     }
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-            before += acc;
+            before += (unsigned long long)wave_sum(acc) + prefix;
             if (retry) {
                 if (++spins > kSelectSpinLimit) {
                     gave_up = true;
@@ -156,15 +167,93 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
             } else if (!done) {
                 pos -= 64 * kSelectWindow;
             }
+            if (!done) poll_issue(pos, s);
         }
         if (lane == 0)
             __hip_atomic_store(state + q, (2ull << 62) | ((before + q_hits) & kSelectValueMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return before;
     };
 
-    // ids of chunk q (its words parked in `pk`), tile by tile.  Sparse tiles (<= 64 ids: the usual case of a selective
-    // predicate) write their few ids straight from the lanes; denser ones go through the LDS stage.
-    auto expand = [&](uint64_t q, int ntiles_q, uint32_t(*pk)[64 * WORDS], unsigned long long out) {
+    // ---- expansion of chunk q (its words parked in `pk`) -------------------------------------------------------------
+    // Part A needs no prefix: the lane's words of ALL tiles of the chunk in one batch of LDS reads, their counts, and
+    // the per-tile prefix sums over the wave two tiles at a time (16-bit fields: a tile has at most 8192 ids) -- K / 2
+    // independent DPP chains instead of one dependent chain per tile with an LDS round trip and a readlane in between
+    // (one wave per SIMD: nothing else hides those latencies; the per-tile form cost 1400 cycles per tile).
+    struct ChunkWords {
+        uint32_t b[K][WORDS];
+        uint32_t cnt[K];  // the lane's ids per tile
+        uint32_t incl[K]; // inclusive prefix over the lanes
+        uint32_t tot[K];  // wave-uniform
+    };
+    auto count_chunk = [&](int ntiles_q, uint32_t(*pk)[64 * WORDS], ChunkWords &cw) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            cw.cnt[k] = 0;
+#pragma unroll
+            for (int j = 0; j < WORDS; j++) {
+                const uint32_t w = pk[k][lane * WORDS + j];
+                cw.b[k][j] = k < ntiles_q ? w : 0u; // (tiles behind the column: stale words of an earlier chunk)
+                cw.cnt[k] += __builtin_popcount(cw.b[k][j]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < K / 2; m++) {
+            const uint32_t sc = wave_inclusive_scan(cw.cnt[2 * m] | (cw.cnt[2 * m + 1] << 16));
+            cw.incl[2 * m] = sc & 0xffffu;
+            cw.incl[2 * m + 1] = sc >> 16;
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+            cw.tot[2 * m] = t & 0xffffu;
+            cw.tot[2 * m + 1] = t >> 16;
+        }
+    };
+
+    // Part B: sparse tiles (<= 64 ids: the usual case of a selective predicate) write their few ids straight from the
+    // lanes; denser ones go through the LDS stage, tile by tile.
+    auto expand = [&](uint64_t q, int ntiles_q, uint32_t(*pk)[64 * WORDS], unsigned long long out, const ChunkWords &cw) {
+        bool any_dense = false;
+        {
+            uint64_t *dst = a.rowids + out;
+            const unsigned long long room64 = out >= a.capacity ? 0ull : a.capacity - out;
+            const uint32_t room = room64 > 0xffffffffull ? 0xffffffffu : (uint32_t)room64;
+            uint32_t off = 0; // ids of the chunk in front of tile k
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint32_t total = cw.tot[k];
+                if (total > 64u) any_dense = true;
+                if (total != 0u && total <= 64u) { // wave-uniform
+                    // one loop over the lane's whole run (lowest set bit of the first non-empty word): the wave iterates
+                    // max-hits-per-lane times (1-2 for a selective predicate), not once per word and hit
+                    uint32_t b[WORDS];
+#pragma unroll
+                    for (int j = 0; j < WORDS; j++) b[j] = cw.b[k][j];
+                    uint32_t o = off + cw.incl[k] - cw.cnt[k];
+                    const uint64_t r0 = a.first_row + (q * K + k) * G::TILE_VALUES + lane * VPL;
+                    uint32_t left = cw.cnt[k];
+                    while (left) {
+                        uint32_t w, jb;
+                        if constexpr (WORDS == 4) {
+                            w = b[0] ? b[0] : (b[1] ? b[1] : (b[2] ? b[2] : b[3]));
+                            jb = b[0] ? 0u : (b[1] ? 32u : (b[2] ? 64u : 96u));
+                        } else {
+                            w = b[0] ? b[0] : b[1];
+                            jb = b[0] ? 0u : 32u;
+                        }
+                        const uint32_t i = (uint32_t)__builtin_ctz(w);
+                        if (o < room) dst[o] = r0 + jb + i;
+                        o++;
+                        left--;
+                        const uint32_t cleared = w & (w - 1);
+                        if constexpr (WORDS == 4) {
+                            if (jb == 0) b[0] = cleared; else if (jb == 32) b[1] = cleared; else if (jb == 64) b[2] = cleared; else b[3] = cleared;
+                        } else {
+                            if (jb == 0) b[0] = cleared; else b[1] = cleared;
+                        }
+                    }
+                }
+                off += total;
+            }
+        }
+        if (!any_dense) return;
 #pragma unroll 1
         for (int k = 0; k < ntiles_q; k++) {
             uint32_t b[WORDS];
@@ -174,38 +263,10 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
                 b[j] = pk[k][lane * WORDS + j];
                 cnt += __builtin_popcount(b[j]);
             }
-            if (__ballot(cnt != 0) == 0) continue; // nothing in this tile
             const uint32_t incl = wave_inclusive_scan(cnt);
             const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
             const uint64_t row0 = a.first_row + (q * K + k) * G::TILE_VALUES;
-            if (total <= 64) {
-                // one loop over the lane's whole run (lowest set bit of the first non-empty word): the wave iterates
-                // max-hits-per-lane times (1-2 for a selective predicate), not once per word and hit
-                uint64_t *dst = a.rowids + out;
-                uint32_t o = incl - cnt;
-                const uint32_t room = out >= a.capacity ? 0u : (a.capacity - out > 64 ? 64u : (uint32_t)(a.capacity - out));
-                const uint64_t r0 = row0 + lane * VPL;
-                uint32_t left = cnt;
-                while (left) {
-                    uint32_t w, jb;
-                    if constexpr (WORDS == 4) {
-                        w = b[0] ? b[0] : (b[1] ? b[1] : (b[2] ? b[2] : b[3]));
-                        jb = b[0] ? 0u : (b[1] ? 32u : (b[2] ? 64u : 96u));
-                    } else {
-                        w = b[0] ? b[0] : b[1];
-                        jb = b[0] ? 0u : 32u;
-                    }
-                    const uint32_t i = (uint32_t)__builtin_ctz(w);
-                    if (o < room) dst[o] = r0 + jb + i;
-                    o++;
-                    left--;
-                    const uint32_t cleared = w & (w - 1);
-                    if constexpr (WORDS == 4) {
-                        if (jb == 0) b[0] = cleared; else if (jb == 32) b[1] = cleared; else if (jb == 64) b[2] = cleared; else b[3] = cleared;
-                    } else {
-                        if (jb == 0) b[0] = cleared; else b[1] = cleared;
-                    }
-                }
+            if (total <= 64) { // written above
                 out += total;
                 continue;
             }
@@ -241,9 +302,17 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
         }
     };
 
+    // (Tried and dropped: sending the first poll out half a chunk early, from inside the next chunk's tile loop, so that its
+    // round trip passes behind the remaining tiles -- 0.267 -> 0.294 ms at 1e9 x 9 bit, 1/512: the branch and the 32 live
+    // registers in the tile loop cost the decode more than the poll's latency.)
     auto finish = [&](uint64_t q, unsigned long long q_hits, int ntiles_q, uint32_t(*pk)[64 * WORDS]) {
-        const unsigned long long before = (a.flags & 4u) ? 0ull : resolve(q, q_hits); // (flags: tuning aids, ablations)
-        if (q_hits && !gave_up && !(a.flags & 2u)) expand(q, ntiles_q, pk, before);
+        const bool look_back = !(a.flags & 4u), want_ids = q_hits && !(a.flags & 2u); // (flags: tuning aids, ablations)
+        unsigned long long s[kSelectWindow];
+        if (look_back && q > 0) poll_issue((int64_t)q - 1, s);
+        ChunkWords cw;
+        if (want_ids) count_chunk(ntiles_q, pk, cw); // needs no prefix: in front of the poll's evaluation
+        const unsigned long long before = look_back ? resolve(q, q_hits, s) : 0ull;
+        if (want_ids && !gave_up) expand(q, ntiles_q, pk, before, cw);
         if (q == nchunks - 1 && lane == 0) a.hits[0] = gave_up ? ~0ull : before + q_hits; // the column's hit count
     };
 
