@@ -175,8 +175,15 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         // linear rows of 9 .. 1024 keys: lanes in memory order (shared_linear_kernel).  It needs two blocks per CU to hide its
         // lookups: tables too big for that -- P = 1024 at c <= 10 -- stay on the per-group kernel unless hit counts are
         // wanted (2.5e8 x 9 bit, P = 1024: 13.5 against 10.2 ms without, 15.6 against 17.8 with).  (flags bit 1: the older kernels, A/B)
-        const bool lin_rows = linear && P > 8 && lut_fits<C, VPL>(P) && !(r.scan.flags & 2u) &&
-                              (2 * ((size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES + lut_static_lds<C, VPL>()) <= 160 * 1024 || r.scan.hits);
+        // Digit-table widths (c > 10) leave it to the per-group kernel beyond 256 keys (beyond 128 without hit counts at c > 16):
+        // every lane of a row decodes the row again and looks up ceil(c/8) digits, and lanes idle when ceil(P/32) is not a
+        // power of two (2.5e8 rows, with / without hit counts, TB/s: c = 13, P = 257: 1.6 / 1.9 against 2.2 / 2.3; P = 600:
+        // 1.2 / 1.2 against 2.4 / 2.6; c = 17, P = 257: 1.3 / 1.4 against 1.5 / 2.7; but P = 150: 1.9 / 2.3 against 1.4 / 1.8,
+        // and c = 9, P = 300: 2.7 / 3.1 against 2.2 / 2.3).
+        const bool lin_pays = C <= 10 || (C <= 16 ? P <= 256 : (P <= 128 || (r.scan.hits && P <= 256)));
+        const bool lin_rows = linear && P > 8 && lut_fits<C, VPL>(P) && !(r.scan.flags & 2u) && lin_pays &&
+                              (2 * ((size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES + lut_static_lds<C, VPL>()) <= 160 * 1024 ||
+                               (r.scan.hits && WideLutGeom<C>::SINGLE));
         if (r.choice_out) { // introspection (mi355_shared_scan_kernel): which kernel family would run, nothing is launched
             *r.choice_out = P <= 8 ? 0 : lin_rows ? 4 : (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) ? 1 : lut_fits<C, VPL>(P) ? 2 : 3;
             break;
@@ -211,7 +218,10 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 allow_dynamic_lds<shared_linear_kernel<C, 2, 1>>(max_dyn, r.device);
                 allow_dynamic_lds<shared_linear_kernel<C, 2, 2>>(max_dyn, r.device);
                 const dim3 lgrid(grid_for(ntiles, r.max_blocks_per_cu > 0 ? r.max_blocks_per_cu : 4, r.num_cus));
-                if (P == 16)
+                // P = 16: two rows per 32-byte piece only with the digit tables (c > 10: 4.0 / 4.8 TB/s against 3.2 / 4.2 with one
+                // row per piece at c = 12); at c <= 10 one row per piece wins (c = 5: 3.0 / 4.7 against 2.0 / 4.1, c = 9: 3.9 /
+                // 4.8 against 3.5 / 4.9 with / without hit counts).  (flags bit 4: one row per piece everywhere, for A/B)
+                if (P == 16 && C > 10 && !(r.scan.flags & 16u))
                     hipLaunchKernelGGL((shared_linear_kernel<C, 2, 2>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);
                 else
                     hipLaunchKernelGGL((shared_linear_kernel<C, 2, 1>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);

@@ -385,9 +385,8 @@ def test_linear_layout_lanes_in_memory_order(O, eng, L, c, P):
     """shared_linear_kernel (linear rows of 16 .. 1024 keys, a power of two): every width class, columns ending inside
     a row (n % 8 != 0), on a row boundary inside a tile, on a tile boundary and inside the first piece; with hit counts
     (packed byte counters) and without; duplicate and out-of-range keys"""
-    choice = L.mi355_shared_scan_kernel(eng._ctx, c, P, 1, 1)
-    if choice != b"shared_linear_kernel":
-        pytest.skip(f"tables of {P} keys at c={c} do not fit LDS: {choice}")
+    # (wide widths with many keys stay on the per-group kernels -- width_group.hip lin_pays -- and tables that do not fit
+    # LDS on the compare chain: the same bytes are required of whichever kernel runs)
     rng = np.random.default_rng(c * 100 + P)
     for n in (4096 * 3 + 77, 4096 * 2 + 16, 4096 * 2, 5):
         vals, col = make_column(O, eng, n, c, 6100 + c + P + n)
@@ -415,9 +414,8 @@ def test_linear_layout_any_key_count(O, eng, L, c, P):
     output untouched, columns ending inside a row / on a row boundary / on a tile boundary / inside the first piece."""
     import torch
 
-    choice = L.mi355_shared_scan_kernel(eng._ctx, c, P, 1, 1)
-    if choice != b"shared_linear_kernel":
-        pytest.skip(f"tables of {P} keys at c={c} do not fit LDS: {choice}")
+    # (wide widths with many keys stay on the per-group kernels -- width_group.hip lin_pays -- and tables that do not fit
+    # LDS on the compare chain: the same bytes are required of whichever kernel runs)
     rng = np.random.default_rng(c * 10000 + P)
     for n in (4096 * 3 + 77, 4096 * 2 + 16, 4096 * 2, 5):
         vals, col = make_column(O, eng, n, c, 7100 + c + P + n)
