@@ -296,8 +296,10 @@ MI355_API int mi355_sharded_scan_range_dev(mi355_ctx *ctx, mi355_comm *comm, con
 /* name of the HIP kernel a given op dispatches to at width c ("scan_eq", "scan_range", "shared_scan",
  * "decompress", "pack"); returns NULL for unknown ops */
 MI355_API const char *mi355_kernel_name(const char *op, unsigned c);
-/* kernel family a shared scan of P keys at width c dispatches to (nothing is launched): "shared_lut_kernel" (P <= 8),
- * "shared_lut_kernel(multi-pass)", "shared_wide_kernel", "shared_general_kernel" (tables do not fit in LDS) */
+/* kernel family a shared scan of P keys at width c dispatches to (nothing is launched): "scan_burst_kernel" (P = 1),
+ * "shared_pair_kernel" (P = 2), "shared_lut_kernel" (P <= 8), "shared_lut_kernel(multi-pass)", "shared_wide_kernel" (stands
+ * for the 32-keys-per-lookup kernels), "shared_linear_kernel" (linear rows, lanes in memory order), "shared_general_kernel"
+ * (tables do not fit in LDS) */
 MI355_API const char *mi355_shared_scan_kernel(mi355_ctx *ctx, unsigned c, unsigned P, int layout, int with_hits);
 /* rows per wave tile of the scan kernels at width c (shard boundaries should be multiples of it) */
 MI355_API uint64_t mi355_tile_values(unsigned c);

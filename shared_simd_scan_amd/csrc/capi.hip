@@ -1131,8 +1131,8 @@ const char *mi355_shared_scan_kernel(mi355_ctx *ctx, unsigned c, unsigned P, int
     r.scan.hits = with_hits ? &dummy : nullptr;
     if (launch(ctx, r) != MI355_OK) return nullptr;
     static const char *const names[] = {"shared_lut_kernel", "shared_lut_kernel(multi-pass)", "shared_wide_kernel", "shared_general_kernel",
-                                        "shared_linear_kernel"};
-    return choice >= 0 && choice < 5 ? names[choice] : nullptr;
+                                        "shared_linear_kernel", "shared_pair_kernel"};
+    return choice >= 0 && choice < 6 ? names[choice] : nullptr;
 }
 
 uint64_t mi355_tile_values(unsigned c)

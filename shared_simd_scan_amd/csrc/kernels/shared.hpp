@@ -111,6 +111,92 @@ __global__ __launch_bounds__(kBlockThreads) void shared_general_kernel(ScanArgs 
     hits_finalize(a, P, lane);
 }
 
+// ---- shared scan, exactly two keys: compares, not lookups -------------------------------------------
+// The one-pass LUT kernel below does the work of eight keys whatever P is (a byte lookup per value and the full 8 x 8
+// bit transposes): P = 2, 3, 4 all take the time of P = 4 (2.5e8 x 9 bit: 0.079 / 0.076 / 0.077 ms -- P = 2 moves
+// 4.3 TB/s where P = 4 moves 5.3).  Two keys cost the equality scan's decode twice (v_cmp + v_addc per value and key,
+// the extraction shared): VALU 0.04 ms per 2.5e8 values, below the column stream.  The scan's geometry (128 values per lane
+// for c <= 16: one 16-byte store per key and lane), the next tile's DMA in flight, a counted vmcnt past the result stores.
+// Linear layout: a row is (key 0 byte, key 1 byte), the lane's rows 2 x WORDS x 4 contiguous bytes (v_perm_b32 interleave).
+template <int C, int AUX_, int VPL>
+__global__ __launch_bounds__(kBlockThreads) void shared_pair_kernel(ScanArgs a)
+{
+    using G = ScanGeom<C, VPL>;
+    constexpr int WORDS = G::WORDS;
+    constexpr int AUX = AUX_ & 15;
+    constexpr int NTS = (AUX_ & 32) ? 2 : ((AUX_ & 16) ? 1 : 0); // result stores: 1 non-temporal, 2 write-through (sc1)
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t k0 = a.key[0], k1 = a.key[1]; // (a key outside [0, 2^C) equals no value: nothing to check)
+    const bool linear = a.layout != 0;
+    uint32_t hits0 = 0, hits1 = 0;
+
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+    int behind = 0; // result stores issued after the DMA the next wait is for
+    while (tile < tc.ntiles) {
+        if (behind == 2)
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (behind == 1)
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t w[G::LANE_DWORDS];
+        read_lane_data<C, VPL>(lds_wave, lane, w);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint64_t next = tile + stride;
+        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        uint32_t r0[1][WORDS], r1[1][WORDS];
+#pragma unroll
+        for (int j = 0; j < WORDS; j++) r0[0][j] = r1[0][j] = 0;
+        decode_step1<C, VPL, 31, kModeEq, G::LANE_DWORDS>(w, r0, k0, 0u);
+        decode_step1<C, VPL, 31, kModeEq, G::LANE_DWORDS>(w, r1, k1, 0u);
+        if (tile < tc.nfull) {
+#pragma unroll
+            for (int j = 0; j < WORDS; j++) {
+                hits0 += __builtin_popcount(r0[0][j]);
+                hits1 += __builtin_popcount(r1[0][j]);
+            }
+            if (!linear) {
+                uint8_t *dst = a.out + tile * G::BITMAP_BYTES + lane * (WORDS * 4);
+                store_words<WORDS, NTS>(dst, r0[0]);
+                store_words<WORDS, NTS>(dst + a.out_stride, r1[0]);
+                behind = 2;
+            } else {
+                uint32_t y[2 * WORDS]; // rows 4j .. 4j+3 of the lane: (key 0, key 1) byte pairs
+#pragma unroll
+                for (int j = 0; j < WORDS; j++) {
+                    y[2 * j] = __builtin_amdgcn_perm(r1[0][j], r0[0][j], 0x05010400u);
+                    y[2 * j + 1] = __builtin_amdgcn_perm(r1[0][j], r0[0][j], 0x07030602u);
+                }
+                uint8_t *dst = a.out + (tile * G::BITMAP_BYTES + (uint64_t)lane * (WORDS * 4)) * 2;
+#pragma unroll
+                for (int i = 0; i < 2 * WORDS; i += 4) {
+                    const uint32_t v[4] = {y[i], y[i + 1], y[i + 2], y[i + 3]};
+                    store_words<4, NTS>(dst + 4 * i, v);
+                }
+                behind = WORDS / 2;
+            }
+        } else {
+            uint8_t *dst = linear ? a.out + (tile * G::BITMAP_BYTES + (uint64_t)lane * (WORDS * 4)) * 2
+                                  : a.out + tile * G::BITMAP_BYTES + lane * (WORDS * 4);
+            hits0 += tc.finish_tail(tile, r0[0], dst, linear ? 2 : 1, lane);
+            hits1 += tc.finish_tail(tile, r1[0], linear ? dst + 1 : dst + a.out_stride, linear ? 2 : 1, lane);
+            behind = 0;
+        }
+        tile = next;
+    }
+    if (a.hits) {
+        hits_add(a, 0, wave_sum(hits0), lane);
+        hits_add(a, 1, wave_sum(hits1), lane);
+    }
+    hits_finalize(a, 2, lane);
+}
+
 // ---- shared scan through an LDS lookup table ------------------------------------------------------
 // v_cmp / v_addc_co run at HALF rate on gfx950 (4.1 cycles per wave-instruction per SIMD against 2.3 for a plain
 // VOP2 op; tools/ubench_valu.hip), so the compare chain above costs 8 keys x 2 x 4.1 = 66 cycles per value and

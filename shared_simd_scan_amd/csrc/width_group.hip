@@ -185,10 +185,32 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                               (2 * ((size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES + lut_static_lds<C, VPL>()) <= 160 * 1024 ||
                                (r.scan.hits && WideLutGeom<C>::SINGLE));
         if (r.choice_out) { // introspection (mi355_shared_scan_kernel): which kernel family would run, nothing is launched
-            *r.choice_out = P <= 8 ? 0 : lin_rows ? 4 : (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) ? 1 : lut_fits<C, VPL>(P) ? 2 : 3;
+            *r.choice_out = (P == 2 && !(r.scan.flags & 32u)) ? 5 : P <= 8 ? 0 : lin_rows ? 4 : (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) ? 1 : lut_fits<C, VPL>(P) ? 2 : 3;
             break;
         }
-        if (P <= 8) { // LDS lookup table, one pass, deferred stores
+        if (P == 2 && !(r.scan.flags & 32u)) { // two keys: the equality scan's decode twice (flags bit 5: the LUT kernel, A/B)
+            // per-predicate: the scan's geometry (128 values per lane at c <= 16: a 16-byte store per key and lane); linear:
+            // 64 values per lane, so that the lane's 16 row bytes are ONE store and an instruction writes 1 KiB of whole
+            // lines (with 128 the lane's 32 bytes left as two instructions of half lines: write-through stores turned
+            // them into partial-line writes -- c = 12: 4.7 TB/s against 5.5 for the LUT kernel it was to replace)
+            auto go = [&](auto vpl_c) {
+                constexpr int PVPL = decltype(vpl_c)::value;
+                using PG = ScanGeom<C, PVPL>;
+                const uint64_t ptiles = (r.scan.n + PG::TILE_VALUES - 1) / PG::TILE_VALUES;
+                static const int pbpc = blocks_per_cu(shared_pair_kernel<C, 34, PVPL>);
+                const dim3 pgrid(grid_for(ptiles, scan_bpc(pbpc, PG::TILE_BYTES, r), r.num_cus));
+                // result stores as in launch_lut8: write-through below 768 MiB of output, non-temporal beyond
+                const int spol = r.scan_nt_stores < 0 ? ((r.scan.n / 8) * P > (768ull << 20) ? 1 : 2) : r.scan_nt_stores;
+                if (spol == 1)
+                    hipLaunchKernelGGL((shared_pair_kernel<C, 18, PVPL>), pgrid, dim3(kBlockThreads), 0, r.stream, r.scan);
+                else
+                    hipLaunchKernelGGL((shared_pair_kernel<C, 34, PVPL>), pgrid, dim3(kBlockThreads), 0, r.stream, r.scan);
+            };
+            if (linear)
+                go(std::integral_constant<int, 64>{});
+            else
+                go(std::integral_constant<int, scan_vpl(C, kModeEq)>{});
+        } else if (P <= 8) { // LDS lookup table, one pass, deferred stores
             // 128 values per lane (16-byte result stores, 1 KiB per wave and key) where the tile, the table and the linear
             // stage fit in LDS and the registers hold 2 x 32 result dwords: c <= 12
             if constexpr (C <= 12) {

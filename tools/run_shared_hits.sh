@@ -1,5 +1,10 @@
 #!/bin/bash
 set -e
 out=gpurun_out/shits; mkdir -p $out; rm -f $out/*
-python -m pytest tests/test_gpu_parity.py -q -x -k "shared or linear" > $out/test.log 2>&1
-python tools/sweep_p.py --P 9,11,13,15,17,23,27,31,32,33,40,47,63,64,65,95,127,128,257,511 --layouts linear --hits 1,0 --burst 4 --reps 3 > $out/lin_odd.log 2>&1
+python -m pytest tests/test_gpu_parity.py -q -x -k "shared or linear or golden or fuzz or cfg4 or 2_pow_32 or store_policy" > $out/test.log 2>&1
+for c in 3 5 7 9 12 16 17 25; do
+  python tools/sweep_p.py --bits $c --P 2 --burst 10 --reps 5 >> $out/pair.log 2>&1
+  MI355_KERNEL_FLAGS=32 python tools/sweep_p.py --bits $c --P 2 --burst 10 --reps 5 >> $out/lut.log 2>&1
+done
+python tools/sweep_p.py --rows 1000000000 --bits 9 --P 2 --burst 10 --reps 5 >> $out/pair_1e9.log 2>&1
+MI355_KERNEL_FLAGS=32 python tools/sweep_p.py --rows 1000000000 --bits 9 --P 2 --burst 10 --reps 5 >> $out/lut_1e9.log 2>&1
