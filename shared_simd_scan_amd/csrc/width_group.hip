@@ -184,8 +184,13 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         const bool lin_rows = linear && P > 8 && lut_fits<C, VPL>(P) && !(r.scan.flags & 2u) && lin_pays &&
                               (2 * ((size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES + lut_static_lds<C, VPL>()) <= 160 * 1024 ||
                                (r.scan.hits && WideLutGeom<C>::SINGLE));
+        // Per-predicate bitmaps at the widths of three or four table digits with few keys: the compare chain (16 v_cmp + v_addc
+        // per value) beats three or four LDS lookups + ANDs per value at two waves per SIMD (2.5e8 rows, with hit counts, TB/s:
+        // c = 17, P = 16: 3.1 against 2.7; c = 25: 3.4 against 2.5; c = 32: 4.0 against 2.5 and P = 24: 3.4 against 2.8; from
+        // P = 32 on the tables win again; linear rows go to shared_linear_kernel, which beats both).
+        const bool chain_pays = !linear && C >= 17 && P <= (C >= 25 ? 24u : 16u);
         if (r.choice_out) { // introspection (mi355_shared_scan_kernel): which kernel family would run, nothing is launched
-            *r.choice_out = (P == 2 && !(r.scan.flags & 32u)) ? 5 : P <= 8 ? 0 : lin_rows ? 4 : (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) ? 1 : lut_fits<C, VPL>(P) ? 2 : 3;
+            *r.choice_out = (P == 2 && !(r.scan.flags & 32u)) ? 5 : P <= 8 ? 0 : lin_rows ? 4 : (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) ? 1 : (lut_fits<C, VPL>(P) && !chain_pays) ? 2 : 3;
             break;
         }
         if (P == 2 && !(r.scan.flags & 32u)) { // two keys: the equality scan's decode twice (flags bit 5: the LUT kernel, A/B)
@@ -228,7 +233,8 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
             allow_dynamic_lds<shared_lut_kernel<C, 2, VPL, 1, true>>((int)(160 * 1024 - lut_static_lds<C, VPL>()), r.device);
             hipLaunchKernelGGL((shared_lut_kernel<C, 2, VPL, 1, true>), dim3(grid_for(ntiles, lut_bpc(8), r.num_cus)),
                                dim3(kBlockThreads), dyn, r.stream, r.scan);
-        } else if (lut_fits<C, VPL>(P)) { // one dword-entry lookup table per 32 keys, in dynamic LDS
+        } else if (lut_fits<C, VPL>(P) && !(r.scan.flags & 64u) && !chain_pays) { // one dword-entry lookup table per 32 keys, in dynamic LDS
+            // (flags bit 6: the compare chain, for A/B)
             const size_t dyn = (size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES;
             const int max_dyn = (int)(160 * 1024 - lut_static_lds<C, VPL>());
             allow_dynamic_lds<shared_wide_kernel<C, 2, VPL, 1>>(max_dyn, r.device);
