@@ -1183,14 +1183,14 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
 // that leave the L2 partly written cost a read-modify-write in ECC-protected HBM (the same effect made per-predicate
 // bitmaps at a non-line-multiple stride up to 2x slower).  Here the lanes of a wave own CONSECUTIVE pieces of the
 // output: a row's P bytes are T = ceil(P/32) pieces of 32 bytes (the last one P - 32 (T-1) bytes), one per table of 32
-// keys; lane l of a step has table l mod Q, Q = T rounded up to a power of two (lanes whose table does not exist idle:
-// none when P is a power of two), and row l / Q -- so a wave step writes 64 / Q whole rows back to back, 2 KiB
+// keys; lane l of a step has table l mod T and row l / T (the 64 mod T lanes behind the last whole row idle: none when
+// T is a power of two) -- so a wave step writes 64 / T whole rows back to back, 2 KiB
 // contiguous when P is a multiple of 32.  A lane fetches the c bytes of its row from the tile's LDS image (lanes of one row
 // read the same words: broadcast), shifts them into place with byte-granular funnel shifts and decodes the 8 values at
 // compile-time offsets; 8 lookups in ITS table and one 8 x 32 bit transpose (group form) give the 32 bytes.  Pieces
 // start at any byte when P is not a multiple of 16: plain unaligned 16-byte stores (the hardware runs in unaligned-access
 // mode), a short last piece as two overlapping stores (store_row_piece).  Hit counts: per-byte population counts of the 32 result bytes,
-// summed in packed byte counters per lane (a lane keeps its table: Q divides 64), flushed to the block's LDS counters
+// summed in packed byte counters per lane (a lane keeps its table from step to step), flushed to the block's LDS counters
 // every 31 steps; from P = 128 on (c <= 12) a histogram of the values instead.
 // RP = rows per 32-byte piece: 1 (a piece = up to 32 keys of one row), or 2 for P = 16 (a piece = two whole rows).
 struct __attribute__((packed, aligned(1))) Unaligned8 {
@@ -1265,8 +1265,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
     uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
     const uint32_t P = a.nkeys;
     const uint32_t T = RP == 1 ? (P + 31) / 32 : 1;                 // tables of 32 keys per row
-    const uint32_t qshift = T > 1 ? 32 - __builtin_clz(T - 1) : 0;  // Q = T rounded up to a power of two: 1, 2, 4, ... 32
-    const uint32_t Q = 1u << qshift;
+    const uint32_t rows_per_step = 64u / T;                         // whole rows a wave step covers; 64 mod T lanes idle
     const uint32_t last_bytes = RP == 1 ? P - 32 * (T - 1) : 32;    // bytes of a row's last piece, 1..32
     const bool aligned16 = (P & 15u) == 0;                          // every piece starts on a 16-byte boundary
     const bool use_hist = HIST && P >= 128;
@@ -1288,12 +1287,14 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
     }
     __syncthreads();
 
-    // the lane's table is the same in every step (Q divides 64); its first row advances by 64 RP / Q per step
-    const uint32_t quarter = (uint32_t)lane & (Q - 1);
-    const bool has_table = quarter < T; // (Q > T: the lanes of the tables that do not exist sit the steps out)
-    const uint32_t row_first = ((uint32_t)lane >> qshift) * RP;
-    const uint32_t row_step = (64u >> qshift) * RP;
-    const uint32_t nsteps = (uint32_t)ROWS * Q / (64 * RP);
+    // lane l has table l mod T and, in step s, row l / T + s * (64 / T): its table is the same in every step, and the
+    // lanes of a step cover 64 / T consecutive rows completely (the 64 mod T lanes behind them sit the steps out: none
+    // when T is a power of two; rounding T up to one instead idled up to 44 % of the wave -- T = 9: 2.2 -> 3.x TB/s)
+    const uint32_t quarter = (uint32_t)lane % T;
+    const bool has_table = (uint32_t)lane < rows_per_step * T;
+    const uint32_t row_first = ((uint32_t)lane / T) * RP;
+    const uint32_t row_step = rows_per_step * RP;
+    const uint32_t nsteps = ((uint32_t)ROWS + row_step - 1) / row_step;
     const uint32_t *const table = lut + (has_table ? quarter : 0u) * L::TABLE_DWORDS;
     const uint32_t piece_bytes = quarter + 1 == T ? last_bytes : 32u;
     // histogram hit counts: the T lanes of a row share its values -- value i belongs to the lane of table i mod T

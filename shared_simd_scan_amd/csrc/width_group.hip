@@ -175,12 +175,13 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         // linear rows of 9 .. 1024 keys: lanes in memory order (shared_linear_kernel).  It needs two blocks per CU to hide its
         // lookups: tables too big for that -- P = 1024 at c <= 10 -- stay on the per-group kernel unless hit counts are
         // wanted (2.5e8 x 9 bit, P = 1024: 13.5 against 10.2 ms without, 15.6 against 17.8 with).  (flags bit 1: the older kernels, A/B)
-        // Digit-table widths (c > 10) leave it to the per-group kernel beyond 256 keys (beyond 128 without hit counts at c > 16):
-        // every lane of a row decodes the row again and looks up ceil(c/8) digits, and lanes idle when ceil(P/32) is not a
-        // power of two (2.5e8 rows, with / without hit counts, TB/s: c = 13, P = 257: 1.6 / 1.9 against 2.2 / 2.3; P = 600:
-        // 1.2 / 1.2 against 2.4 / 2.6; c = 17, P = 257: 1.3 / 1.4 against 1.5 / 2.7; but P = 150: 1.9 / 2.3 against 1.4 / 1.8,
-        // and c = 9, P = 300: 2.7 / 3.1 against 2.2 / 2.3).
-        const bool lin_pays = C <= 10 || (C <= 16 ? P <= 256 : (P <= 128 || (r.scan.hits && P <= 256)));
+        // Digit-table widths (c > 10) leave it to the per-group kernel beyond 320 keys (beyond 160 without hit counts at c > 16):
+        // every lane of a row decodes the row again and looks up ceil(c/8) digits, and the tables leave room for two blocks
+        // per CU only (2.5e8 rows, with / without hit counts, TB/s, shared_linear_kernel against the per-group kernel: c = 13,
+        // P = 300: 2.6 / 2.9 against 2.2 / 2.2, P = 400: 2.1 / 2.3 against 2.4 / 2.7, P = 600: 1.7 / 1.8 against 2.4 / 2.6;
+        // c = 17, P = 150: 2.6 / 2.8 against 1.4 / 1.8, P = 200: 2.6 / 2.8 against 1.5 / 3.0, P = 300: 2.1 / 2.2 against 1.5 / 2.5;
+        // c = 9, P = 300: 3.6 / 4.1 against 2.2 / 2.3).
+        const bool lin_pays = C <= 10 || (C <= 16 ? P <= 320 : P <= (r.scan.hits ? 320u : 160u)) || (r.scan.flags & 128u); // (bit 7: always, A/B)
         const bool lin_rows = linear && P > 8 && lut_fits<C, VPL>(P) && !(r.scan.flags & 2u) && lin_pays &&
                               (2 * ((size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES + lut_static_lds<C, VPL>()) <= 160 * 1024 ||
                                (r.scan.hits && WideLutGeom<C>::SINGLE));
