@@ -424,8 +424,10 @@ template <int WORDS, int NT = 0> __device__ __forceinline__ void store_words(uin
 // ticket sums the replicas into the caller's `hits` array with atomic exchanges that also zero the scratch
 // for the next launch.  One kernel launch per scan.
 constexpr int kHitSlots = 64;
-constexpr int kScratchWords = kHitSlots * kMaxKeys + 8; // replicas + "done" counter (+ diagnostics)
+constexpr int kDoneGroups = 16; // first-level "done" counters, one 128-byte line each (see hits_finalize)
+constexpr int kScratchWords = kHitSlots * kMaxKeys + 8 + kDoneGroups * 16; // replicas + "done" counter (+ diagnostics) + group counters
 constexpr int kScratchDone = kHitSlots * kMaxKeys;
+constexpr int kScratchGroupDone = kScratchDone + 8;
 
 __device__ __forceinline__ void hits_add(const ScanArgs &a, uint32_t k, uint32_t wave_total, int lane)
 {
@@ -438,13 +440,27 @@ __device__ __forceinline__ void hits_add(const ScanArgs &a, uint32_t k, uint32_t
 __device__ __forceinline__ void hits_finalize(const ScanArgs &a, uint32_t P, int lane)
 {
     if (!a.hits) return;
-    __shared__ unsigned long long s_ticket;
+    __shared__ uint32_t s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's adds have been performed
     __syncthreads();
-    if (threadIdx.x == 0)
-        s_ticket = __hip_atomic_fetch_add(a.scratch + kScratchDone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        // Two levels of tickets: same-address device atomics serialise at ~12 ns each, so ONE counter taken by every block cost
+        // a 512-block launch 6 us (a 2e7-row scan takes 6 us without its count).  Block b takes a ticket of group b mod 16
+        // (its own 128-byte line); the block that completes its group takes a ticket of the top counter; the block that
+        // completes that one has seen -- transitively -- every block's ticket, i.e. every block's adds performed.
+        const uint32_t g = blockIdx.x % kDoneGroups;
+        const uint32_t in_group = (gridDim.x - g + kDoneGroups - 1) / kDoneGroups;
+        const uint32_t ngroups = gridDim.x < (unsigned)kDoneGroups ? gridDim.x : (unsigned)kDoneGroups;
+        unsigned long long *const gdone = a.scratch + kScratchGroupDone + g * 16;
+        uint32_t last = 0;
+        if (__hip_atomic_fetch_add(gdone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)in_group - 1) {
+            __hip_atomic_store(gdone, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // zero again for the next launch
+            last = __hip_atomic_fetch_add(a.scratch + kScratchDone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)ngroups - 1;
+        }
+        s_last = last;
+    }
     __syncthreads();
-    if (s_ticket == (unsigned long long)gridDim.x - 1) {
+    if (s_last) {
         // the last block: thread t sums the replicas of keys t, t + 256, ... (consecutive threads = consecutive words of a
         // replica row; the exchanges of one key are independent, so they overlap -- a single wave walking the keys one
         // after the other waited a memory-side round trip per key: 0.36 ms at P = 512)
