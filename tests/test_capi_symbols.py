@@ -70,3 +70,38 @@ def test_oracle_is_not_reachable_from_the_product():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.replace("no CPU fallback", ""), os.path.join(dirpath, f)
     assert "oracle" not in open(os.path.join(ROOT, "include", "mi355_scan.h")).read()
+
+
+def test_header_is_plain_c99_and_links_from_c(L, tmp_path):
+    """the boundary is a C ABI: include/mi355_scan.h compiles as strict C99 (no C++ types, no extensions) and a C program
+    links against the library and calls the entry points that need no device (sizing helpers, shard arithmetic, errors)"""
+    import subprocess
+
+    from shared_simd_scan_amd import build
+
+    src = tmp_path / "c_caller.c"
+    src.write_text(r'''
+#include "mi355_scan.h"
+#include <stdio.h>
+#include <string.h>
+int main(void)
+{
+    uint64_t first = 0, count = 0;
+    if (mi355_compressed_buffer_size(9, 13) != 15 + 256) return 1;
+    if (mi355_scan_output_buffer_size(8) != 1 + 32) return 2;
+    if (mi355_bitmap_stride(1000) != 256) return 3;
+    if (mi355_shard_rows(1000000, 8, 7, &first, &count) != MI355_OK || first + count != 1000000 || first % 8192) return 4;
+    if (mi355_shard_rows(10, 0, 0, &first, &count) == MI355_OK) return 5; /* world = 0: rejected */
+    if (!mi355_last_error() || !strlen(mi355_last_error())) return 6;
+    if (!mi355_kernel_name("scan_eq", 9) || mi355_kernel_name("nonsense", 9)) return 7;
+    if (MI355_TUNE_ALL != (MI355_TUNE_SCAN | MI355_TUNE_COUNT | MI355_TUNE_MASK | MI355_TUNE_DECOMPRESS)) return 8;
+    printf("c99 ok\n");
+    return 0;
+}
+''')
+    exe = tmp_path / "c_caller"
+    libdir = os.path.dirname(build.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-lmi355scan", f"-Wl,-rpath,{libdir}"], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0 and "c99 ok" in res.stdout, (res.returncode, res.stdout, res.stderr)
