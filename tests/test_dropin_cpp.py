@@ -28,8 +28,13 @@ def _compile(src, exe, extra=()):
     return exe
 
 
+NEXT_SRC = os.path.join(ROOT, "tests", "cpp", "next_tests.cpp")
+NEXT_BIN = os.path.join(ROOT, "tests", "cpp", "build", "next_tests")
+
+
 def build_binary():
     _compile(THREADS_SRC, THREADS_BIN, extra=("-pthread",))
+    _compile(NEXT_SRC, NEXT_BIN)
     return _compile(SRC, BIN)
 
 
@@ -56,6 +61,23 @@ def test_dropin_calls_from_eight_host_threads():
     res = subprocess.run([THREADS_BIN], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "All thread tests passed" in res.stdout
+
+
+def test_next_row_host_compiles_with_plain_gxx():
+    build_binary()
+    assert subprocess.run([NEXT_BIN, "--compile-check"]).returncode == 0
+
+
+@pytest.mark.gpu
+def test_cpp_host_drives_the_device_pointer_api():
+    """a plain C++ host (no Python, no HIP headers) on the entry points beyond the reference's surface: resident columns,
+    count-only / fused-mask scans, two columns in one call, IN-list, fused selection with global row ids, shared scans of
+    2 / 5 / 37 keys in both layouts, the tuning call -- against scalar loops over the generator's closed form
+    (tests/cpp/next_tests.cpp)"""
+    build_binary()
+    res = subprocess.run([NEXT_BIN], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "All next-row tests passed" in res.stdout
 
 
 CLI = os.path.join(ROOT, "cli", "shared_simd_scan_mi355")
