@@ -248,6 +248,14 @@ MI355_API int mi355_bitmap_count_dev(mi355_ctx *ctx, const void *bitmap_dev, uin
 MI355_API int mi355_bitmap_to_rowids_dev(mi355_ctx *ctx, const void *bitmap_dev, uint64_t n, uint64_t first_row,
                                          uint64_t *rowids_dev, uint64_t capacity, uint64_t *count_dev);
 
+/* "take": out_dev[i] = value of row rowids_dev[i] of the packed column (row ids as the selection calls above produce them:
+ * first_row + index; any order, duplicates allowed), for i < min(*count_dev, capacity) -- the count is read ON THE DEVICE,
+ * so the call composes with mi355_scan_select_dev / mi355_bitmap_to_rowids_dev without a host round trip.  An id outside
+ * [first_row, first_row + n) yields -1 (at c = 32 indistinguishable from the value 0xffffffff).  packed_dev as everywhere:
+ * readable 8 bytes past the last value (mi355_compressed_buffer_size covers it). */
+MI355_API int mi355_gather_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, uint64_t first_row,
+                               const uint64_t *rowids_dev, const uint64_t *count_dev, uint64_t capacity, int32_t *out_dev);
+
 /* ---- row-range sharding helper (one process per GPU): rank's rows [first, first+count) of an n-row
  * column split over `world` ranks at multiples of 8192 rows, so every shard's packed slice starts 16-byte aligned on
  * a whole value and its bitmap slice on a whole byte.  Pure arithmetic, no device needed. */

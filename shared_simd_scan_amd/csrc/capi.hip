@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "dispatch.hpp"
+#include "extras/gather.hpp"
 #include "kernels.hpp"
 
 using namespace mi355;
@@ -879,6 +880,35 @@ int mi355_bitmap_to_rowids_dev(mi355_ctx *ctx, const void *bitmap_dev, uint64_t 
     hipLaunchKernelGGL(rowid_write_kernel, dim3(grid), dim3(256), 0, ctx->stream, g);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(count_dev, g.chunk_counts + g.nchunks, sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    return MI355_OK;
+}
+
+int mi355_gather_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, uint64_t first_row, const uint64_t *rowids_dev,
+                     const uint64_t *count_dev, uint64_t capacity, int32_t *out_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    CtxLock lk(ctx->mu);
+    if ((rc = check_width(c))) return rc;
+    if ((rc = bind(ctx))) return rc;
+    if (!count_dev) return fail(MI355_E_INVALID, "count_dev is null (the number of ids is read on the device)");
+    if (capacity == 0) return MI355_OK;
+    if (!packed_dev || !rowids_dev || !out_dev) return fail(MI355_E_INVALID, "null device pointer");
+    if ((uintptr_t)packed_dev & 3) return fail(MI355_E_INVALID, "packed_dev must be 4-byte aligned");
+    GatherArgs g;
+    g.packed = (const uint8_t *)packed_dev;
+    g.n = n;
+    g.c = c;
+    g.first_row = first_row;
+    g.rowids = rowids_dev;
+    g.count_dev = count_dev;
+    g.capacity = capacity;
+    g.out = out_dev;
+    // the grid is sized for `capacity` (the count is only known on the device); idle blocks leave at once
+    const uint64_t blocks = (capacity + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < (uint64_t)ctx->num_cus * 16 ? blocks : (uint64_t)ctx->num_cus * 16);
+    hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, ctx->stream, g);
+    HIP_TRY(hipGetLastError());
     return MI355_OK;
 }
 

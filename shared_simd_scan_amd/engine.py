@@ -268,6 +268,20 @@ class ScanEngine:
                                                count.data_ptr()))
         return rowids, count
 
+    def gather(self, col: PackedColumn, rowids: torch.Tensor, count, first_row: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """values of `col` at the row ids a selection produced ("take"): out[i] = value of row rowids[i] for
+        i < min(count, len(rowids)); `count` is the int64[1] device tensor the selection left behind (no host round trip) or
+        an int.  Ids outside the column give -1."""
+        cap = int(rowids.numel())
+        if not torch.is_tensor(count):
+            count = torch.tensor([int(count)], dtype=torch.int64, device=self._dev)
+        if out is None:
+            out = torch.empty(max(cap, 1), dtype=torch.int32, device=self._dev)
+        assert rowids.dtype == torch.int64 and out.dtype == torch.int32 and out.numel() >= cap
+        check(lib().mi355_gather_dev(self._ctx, col.data.data_ptr(), col.n, col.c, first_row, rowids.data_ptr(), count.data_ptr(), cap,
+                                     out.data_ptr()))
+        return out
+
     # ---- shared scans (src/simd_scan_shared.cpp, src/simd_scan_shared_linear.cpp) -----------------
     def shared_scan(self, keys: Sequence[int], col: PackedColumn, layout: str = "per_predicate",
                     out: Optional[torch.Tensor] = None, hits: Optional[torch.Tensor] = None):

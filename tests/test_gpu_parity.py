@@ -471,6 +471,41 @@ def test_linear_layout_up_to_8_keys(O, eng, c, P, vpl):
         eng.set_option("shared_vpl", 0)
 
 
+@pytest.mark.parametrize("c", [1, 5, 9, 12, 17, 31, 32])
+def test_gather_values_at_row_ids(O, eng, c):
+    """mi355_gather_dev ("take"): values at arbitrary row ids (unsorted, duplicates, the last row, ids outside the column ->
+    -1), the count read on the device and capped by the capacity; then the pipeline it is for: predicate on one column ->
+    ascending row ids in one launch -> the values of ANOTHER column at those rows, nothing passing through the host"""
+    import torch
+
+    n = 8192 * 7 + 4099
+    vals, col = make_column(O, eng, n, c, 9900 + c)
+    rng = np.random.default_rng(c)
+    first = 5_000_000_000  # global row ids (a shard far into a table)
+    local = rng.integers(0, n, size=20_000)
+    local[:4] = [n - 1, 0, n - 1, 12345 % n]
+    ids = torch.from_numpy((local + first).astype(np.int64)).cuda()
+    ids[7] = first - 1      # below the shard
+    ids[8] = first + n      # behind it
+    got = eng.gather(col, ids, ids.numel(), first_row=first).cpu().numpy()
+    want = vals[local].astype(np.int64).astype(np.uint32).view(np.int32).copy()
+    want[7] = want[8] = -1
+    assert np.array_equal(got, want)
+    # count on the device smaller than the capacity: the rest of `out` stays untouched
+    out = torch.full((ids.numel(),), -7, dtype=torch.int32, device="cuda")
+    eng.gather(col, ids, torch.tensor([100], dtype=torch.int64, device="cuda"), first_row=first, out=out)
+    assert np.array_equal(out[:100].cpu().numpy(), want[:100]) and bool((out[100:] == -7).all().item())
+    # select on one column, take from another
+    vals2, col2 = make_column(O, eng, n, 12, 9950 + c)
+    key = int(vals[77])
+    expect_rows = np.nonzero(vals == key)[0]
+    rowids, cnt = eng.scan_select("==", key, col, capacity=n, first_row=first)
+    taken = eng.gather(col2, rowids, cnt, first_row=first)
+    k = int(cnt.item())
+    assert k == expect_rows.shape[0]
+    assert np.array_equal(taken[:k].cpu().numpy(), vals2[expect_rows].astype(np.int32))
+
+
 def test_out_of_range_keys_never_match(O, eng):
     """SURVEY 8c hazard 5: keys 515, 1027, 65539, -1 on a 9-bit column -> no hits, zero bitmap."""
     import torch

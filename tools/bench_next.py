@@ -107,6 +107,13 @@ def main():
         t_fused = timed(fused, 5)
         report(f"scan_select (fused), selectivity {name}", t_fused, pk + 8 * cnt,
                f"1 launch, no bitmap in HBM: {3 * nb / 1e6:.0f} MB less traffic, {t_chain / t_fused:.2f}x the chain's speed")
+        if name == "1/512":
+            col_b = eng.generate("splitmix", n, 12, 4242)
+            cnt_dev = torch.tensor([cnt], dtype=torch.int64, device="cuda")
+            taken = torch.empty(cnt, dtype=torch.int32, device="cuda")
+            report(f"gather: another column's values at those {cnt} ids", timed(lambda: eng.gather(col_b, ids[0][:cnt], cnt_dev, out=taken), 10),
+                   12 * cnt, "(\"take\": two dwords per id; algorithmic = 8 B id + 4 B value per row)")
+            del col_b, taken
         del ids
         torch.cuda.empty_cache()
 
