@@ -1,6 +1,7 @@
 // tests/cpp/next_tests.cpp -- a plain C++ host (g++, no HIP, no Python) driving the device-pointer entry points that go
 // beyond the reference's surface: resident columns, count-only and fused-mask scans, two columns in one call, the fused
-// selection vector, IN-lists, shared scans of 2 / 5 / 37 keys in both layouts, load-time tuning.  Expected results are
+// selection vector and the values of another column at those rows, IN-lists, shared scans of 2 / 5 / 37 keys in both
+// layouts, load-time tuning.  Expected results are
 // computed here with scalar loops over the generator's closed form (v[i] = (first + i) % m), not by the oracle.
 //   next_tests --compile-check   : exit 0 without touching a device (CPU build check)
 #include "mi355_scan.h"
@@ -97,6 +98,16 @@ int main(int argc, char **argv)
     std::vector<uint64_t> ids(expect_ids.size());
     OK(mi355_dev_download(ctx, ids.data(), ids_dev, ids.size() * sizeof(uint64_t)));
     REQUIRE(ids == expect_ids);
+    // ... and the values of the OTHER column at those rows ("take"), the count still on the device
+    {
+        void *taken_dev = nullptr;
+        OK(mi355_dev_alloc(ctx, n * sizeof(int32_t), &taken_dev));
+        OK(mi355_gather_dev(ctx, col1, n, c, first, (const uint64_t *)ids_dev, hits_dev, n, (int32_t *)taken_dev));
+        std::vector<int32_t> taken(expect_ids.size());
+        OK(mi355_dev_download(ctx, taken.data(), taken_dev, taken.size() * sizeof(int32_t)));
+        for (size_t k = 0; k < taken.size(); k++) REQUIRE((uint64_t)taken[k] == v1(expect_ids[k] - first));
+        OK(mi355_dev_free(ctx, taken_dev));
+    }
 
     // shared scans: 2 keys (compare kernel), 5 keys (one-pass LUT, packed rows), 37 keys (32 keys per lookup), both layouts
     for (unsigned P : {2u, 5u, 37u}) {
