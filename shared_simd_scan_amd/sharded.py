@@ -236,6 +236,23 @@ class ShardedColumn:
         bitmap, hits = self.engine.scan_range(lo, hi, self.col)
         return self._finish(bitmap, hits, dst)
 
+    def select(self, op: str, a: int, dst: int = 0, b: int = 0):
+        """predicate -> the column's ascending GLOBAL row ids on rank `dst` (None elsewhere) and the total count (an int, on
+        every rank).  Each rank runs the fused selection on its shard (no bitmap anywhere; ids are base_row + row index);
+        the per-rank counts travel as ONE all-reduce of a one-hot vector; every rank's ids are then received at their
+        final offset of the root's id list (shards are row ranges in rank order, so the concatenation is ascending)."""
+        eng, ex, dev = self.engine, self.exchange, self._device()
+        ids, cnt = eng.scan_select(op, a, self.col, capacity=max(self.rows, 1), b=b, first_row=self.base_row + self.first)
+        onehot = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        onehot[self.rank] = cnt.to(dev).reshape(())
+        counts = [int(x) for x in ex.sum_hits(onehot, engine=eng).cpu().tolist()]  # (the host needs them to size the receives)
+        sizes = [8 * k for k in counts]
+        offsets = [sum(sizes[:r]) for r in range(self.world)]
+        out = torch.empty(sum(counts), dtype=torch.int64, device=dev) if self.rank == dst else None
+        local = ids.contiguous().view(torch.uint8)[: sizes[self.rank]]
+        ex.gather_at(local, sizes, offsets, dst, out.view(torch.uint8) if out is not None else None, engine=eng)
+        return out, sum(counts)
+
     def scan_pipelined(self, key: int, dst: int = 0, chunks: int = 4):
         """Same result as scan().  The shard is scanned in `chunks` row ranges (boundaries at multiples of SHARD_ALIGN)
         and the gather of range i is enqueued as soon as its scan is: with the RCCL exchange on a side stream the

@@ -66,6 +66,19 @@ class OracleEngine:
         return torch.from_numpy(bm), torch.tensor([hits], dtype=torch.int64)
 
 
+    _CMP = {"==": lambda v, a, b: v == a, "<": lambda v, a, b: v < a, "between": lambda v, a, b: (v >= a) & (v <= b)}
+
+    def scan_select(self, op, a, col, capacity, b=0, first_row=0):
+        """the fused selection, restated through the oracle's decompress (test stand-in only)"""
+        packed, n, c = col
+        v = self.O.decompress(packed, n, c).astype(np.int64) if n else np.zeros(0, dtype=np.int64)
+        rows = np.nonzero(self._CMP[op](v, a, b))[0].astype(np.int64) + first_row
+        ids = torch.zeros(max(capacity, 1), dtype=torch.int64)
+        k = min(rows.shape[0], capacity)
+        ids[:k] = torch.from_numpy(rows[:k])
+        return ids, torch.tensor([rows.shape[0]], dtype=torch.int64)
+
+
 def worker(rank, world, port, n, c, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -82,8 +95,11 @@ def worker(rank, world, port, n, c, q):
         lo, hi = (1 << c) // 4, (1 << c) // 2
         full_r, hits_r = sc.scan_range(lo, hi, dst=0)
         full_p, hits_p = sc.scan_pipelined(key, dst=0, chunks=3)  # chunked scan + asynchronous gathers: same result
+        ids, nids = sc.select("between", lo, dst=0, b=hi)           # global row ids on the root, the count everywhere
         if rank == 0:
             vals = O.gen_values("splitmix", n, c, 42)
+            want_ids = np.nonzero((vals >= lo) & (vals <= hi))[0].astype(np.int64)
+            assert nids == want_ids.shape[0] and np.array_equal(ids.numpy(), want_ids)
             packed = O.pack(vals, c)
             ref, ref_hits = O.scan_eq(packed, n, c, key)
             ref_r, ref_hits_r = O.scan_range(packed, n, c, lo, hi)
@@ -92,8 +108,9 @@ def worker(rank, world, port, n, c, q):
                   and np.array_equal(full_r.numpy(), ref_r) and int(hits_r.item()) == ref_hits_r)
             q.put(("ok" if ok else "mismatch", sc.ranges))
         else:
-            assert full is None
+            assert full is None and ids is None
             assert int(hits.item()) >= 0  # every rank gets the column-wide count
+            assert nids == int(hits_r.item())
     finally:
         dist.destroy_process_group()
 
@@ -156,8 +173,11 @@ def gpu_worker(rank, world, port, n, c, base_row, q):
         lo, hi = (1 << c) // 4, (1 << c) // 2
         full_r, hits_r = sc.scan_range(lo, hi, dst=0)
         full_p, hits_p = sc.scan_pipelined(key, dst=0, chunks=3)
+        ids, nids = sc.select("between", lo, dst=0, b=hi)  # fused selection per shard, global ids gathered on the root
         if rank == 0:
             vals = O.gen_values("splitmix", n, c, 42, first=base_row)
+            want_ids = np.nonzero((vals >= lo) & (vals <= hi))[0].astype(np.int64) + base_row
+            assert nids == want_ids.shape[0] and ids.is_cuda and np.array_equal(ids.cpu().numpy(), want_ids)
             packed = O.pack(vals, c)
             ref, ref_hits = O.scan_eq(packed, n, c, key)
             ref_r, ref_hits_r = O.scan_range(packed, n, c, lo, hi)
@@ -166,7 +186,7 @@ def gpu_worker(rank, world, port, n, c, base_row, q):
                   and np.array_equal(full_r.cpu().numpy(), ref_r) and int(hits_r.item()) == ref_hits_r)
             q.put(("ok" if ok else "mismatch", sc.ranges))
         else:
-            assert full is None and full_p is None
+            assert full is None and full_p is None and ids is None and nids == int(hits_r.item())
     finally:
         dist.destroy_process_group()
 
