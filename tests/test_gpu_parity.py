@@ -4,6 +4,7 @@ Bit-exact everywhere: this is integer / bit work, there is no tolerance.  Parity
 [0, n) plus the canonical zero tail (DESIGN.md "tail rule"); hits = popcount over [0, n).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1208,6 +1209,79 @@ def test_fuzz_random_shapes_and_predicates(O, eng, seed):
         member = np.isin(v, np.array([k for k in keys if 0 <= k <= vmax], dtype=np.int64))
         bm, hits = eng.scan_in(keys32, col)
         assert np.array_equal(bm.cpu().numpy(), np_bitmap(member)) and int(hits.item()) == int(member.sum()), (c, n, P)
+
+
+FUZZ2_SEEDS = int(os.environ.get("MI355_FUZZ_SEEDS", "10"))  # (a one-off stress run sets it to a few hundred)
+
+
+@pytest.mark.parametrize("seed", list(range(FUZZ2_SEEDS)))
+def test_fuzz_round2_entry_points(O, eng, seed):
+    """seeded random columns through the round-2 entry points, against numpy on the oracle-decoded values: shared scans of
+    ANY key count (biased to the kernel boundaries 2, 8 / 9, 16, 32 / 33, 64, 128, 256 / 257, 320 / 321) in both layouts
+    with and without hit counts, count-only and fused-mask scans, two columns in one call, the fused selection (with a
+    capacity below the count now and then), take-by-row-id.  20 columns per seed."""
+    import torch
+
+    rng = np.random.default_rng(555_000 + seed)
+    pool = [2, 3, 5, 6, 7, 8, 9, 10, 15, 16, 17, 31, 32, 33, 40, 63, 64, 65, 96, 127, 128, 129, 160, 255, 256, 257, 300, 320, 321, 400, 512, 700, 1024]
+    for _ in range(20):
+        c = int(rng.integers(1, 33))
+        tile = 8192 if c <= 16 else 4096
+        n = max(1, int(rng.choice([rng.integers(1, 300), tile * rng.integers(1, 20) + rng.integers(-70, 70), rng.integers(1, 200_000)])))
+        vmax = (1 << c) - 1
+        vals, col = make_column(O, eng, n, c, int(rng.integers(0, 1 << 30)))
+        v = vals.astype(np.int64)
+        nb = (n + 7) // 8
+
+        def pick():
+            cand = [0, vmax, int(vals[int(rng.integers(0, n))]), int(vals[int(rng.integers(0, n))]), int(rng.integers(0, vmax + 1))]
+            if c < 31:
+                cand += [vmax + 3, -1]
+            return int(cand[int(rng.integers(0, len(cand)))])
+
+        # shared scan, any key count
+        P = int(rng.choice(pool)) if rng.integers(0, 4) else int(rng.integers(1, 1025))
+        keys = [pick() for _ in range(P)]
+        keys32 = [k if k < 2 ** 31 else k - 2 ** 32 for k in keys]
+        layout = str(rng.choice(["per_predicate", "linear"]))
+        count = bool(rng.integers(0, 2))
+        out, hits = eng.shared_scan(keys32, col, layout=layout, hits=None if count else False)
+        per_key = np.stack([np_bitmap(v == k) for k in keys])  # [P, nb]
+        got = out.cpu().numpy()
+        if layout == "per_predicate":
+            assert np.array_equal(got[:, :nb], per_key), (seed, c, n, P, layout, count)
+        else:
+            assert np.array_equal(got.reshape(nb, P), per_key.T), (seed, c, n, P, layout, count)
+        if count:
+            assert np.array_equal(hits.cpu().numpy(), np.array([int((v == k).sum()) for k in keys])), (seed, c, n, P, layout)
+        # count-only, fused masks, two columns
+        a, b = sorted((pick(), pick()))
+        p1 = (v >= a) & (v <= b)
+        bm1, h1 = eng.scan_where("between", a, col, b=b)
+        assert np.array_equal(bm1.cpu().numpy(), np_bitmap(p1)) and int(h1.item()) == int(p1.sum()), (seed, c, n, a, b)
+        _, hc = eng.scan_combine("between", a, col, b=b, count_only=True)
+        assert int(hc.item()) == int(p1.sum())
+        k2 = pick()
+        for mop, fn in (("and", lambda p, m: p & m), ("or", lambda p, m: p | m), ("xor", lambda p, m: p ^ m), ("andnot", lambda p, m: m & ~p)):
+            bmm, hm = eng.scan_combine("==", k2, col, mask=bm1, mask_op=mop)
+            e = fn(v == k2, p1)
+            assert np.array_equal(bmm.cpu().numpy(), np_bitmap(e)) and int(hm.item()) == int(e.sum()), (seed, c, n, mop)
+        vals2, col2 = make_column(O, eng, n, c, int(rng.integers(0, 1 << 30)))
+        v2 = vals2.astype(np.int64)
+        b2, h2 = eng.scan2(col, "<=", b, col2, ">", a, combine="or")
+        e2 = (v <= b) | (v2 > a)
+        assert np.array_equal(b2.cpu().numpy(), np_bitmap(e2)) and int(h2.item()) == int(e2.sum()), (seed, c, n, a, b)
+        # fused selection (sometimes with too little room) and take-by-row-id from the second column
+        rows = np.nonzero(p1)[0].astype(np.int64)
+        cap = n if rng.integers(0, 3) else max(1, rows.shape[0] // 2)
+        first = int(rng.choice([0, 1 << 33]))
+        ids, cnt = eng.scan_select("between", a, col, capacity=cap, b=b, first_row=first)
+        assert int(cnt.item()) == rows.shape[0], (seed, c, n, a, b)
+        k = min(cap, rows.shape[0])
+        assert np.array_equal(ids[:k].cpu().numpy(), rows[:k] + first), (seed, c, n, a, b, cap)
+        if k:
+            taken = eng.gather(col2, ids[:k], k, first_row=first)
+            assert np.array_equal(taken[:k].cpu().numpy().view(np.uint32), vals2[rows[:k]]), (seed, c, n)
 
 
 @pytest.mark.parametrize("c", [5, 9, 12, 21])
