@@ -124,7 +124,9 @@ int launch(mi355_ctx *ctx, LaunchReq &r)
     r.scan_nt_stores = ctx->scan_nt_stores;
     r.shared_vpl = ctx->shared_vpl;
     r.scan_burst = ctx->scan_burst;
-    r.scan.flags = ctx->kernel_flags;
+    // the A/B switches of the shared scans (bits 0-7) never reach select_kernel, whose two TIMING ablations (no expansion /
+    // no look-back: wrong ids by construction) live in bits 9 and 10 of the option and arrive as its bits 1 and 2
+    r.scan.flags = r.op == kOpSelect ? ((ctx->kernel_flags >> 8) & 6u) : (ctx->kernel_flags & 0xffu);
     r.scan.scratch = ctx->kernel_scratch;
     if (r.max_blocks_per_cu == 0 && !ctx->tuned_bpc.empty()) {
         const bool scan = r.op == kOpScanEq || r.op == kOpScanRange;

@@ -15,6 +15,6 @@ def timed(fn, reps=20):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / reps
 print("count-only scan", timed(lambda: eng.scan_combine("==", 77, col, hits=hits, count_only=True)))
-for flags, name in ((0, "full"), (2, "no expand"), (4, "no look-back"), (6, "decode + park only")):
+for flags, name in ((0, "full"), (512, "no expand"), (1024, "no look-back"), (1536, "decode + park only")):
     eng.set_option("kernel_flags", flags)
     print(f"select {name:20s}", timed(lambda: eng.scan_select("==", 77, col, capacity=4_000_000)), flush=True)
