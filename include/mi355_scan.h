@@ -256,6 +256,13 @@ MI355_API int mi355_bitmap_to_rowids_dev(mi355_ctx *ctx, const void *bitmap_dev,
 MI355_API int mi355_gather_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, uint64_t first_row,
                                const uint64_t *rowids_dev, const uint64_t *count_dev, uint64_t capacity, int32_t *out_dev);
 
+/* Aggregates of a packed column, optionally only over the rows of a bitmap (SELECT sum(b), count(*), min(b), max(b) WHERE
+ * <mask>): ONE pass at the speed of the column stream, nothing decoded to memory.  out_dev[0] = sum, [1] = count of rows that
+ * counted, [2] = min, [3] = max (values as unsigned c-bit integers; count = 0: sum 0, min UINT64_MAX, max 0).
+ * mask_dev == NULL: every row counts.  Asynchronous on the context's stream. */
+MI355_API int mi355_aggregate_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const void *mask_dev,
+                                  uint64_t *out_dev);
+
 /* ---- row-range sharding helper (one process per GPU): rank's rows [first, first+count) of an n-row
  * column split over `world` ranks at multiples of 8192 rows, so every shard's packed slice starts 16-byte aligned on
  * a whole value and its bitmap slice on a whole byte.  Pure arithmetic, no device needed. */

@@ -12,6 +12,7 @@
 #include "dispatch.hpp"
 #include "extras/gather.hpp"
 #include "kernels.hpp"
+#include "extras/aggregate.hpp"
 
 using namespace mi355;
 
@@ -910,6 +911,30 @@ int mi355_gather_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigne
     const uint64_t blocks = (capacity + 255) / 256;
     const unsigned grid = (unsigned)(blocks < (uint64_t)ctx->num_cus * 16 ? blocks : (uint64_t)ctx->num_cus * 16);
     hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, ctx->stream, g);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+
+int mi355_aggregate_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const void *mask_dev, uint64_t *out_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    CtxLock lk(ctx->mu);
+    if ((rc = check_width(c))) return rc;
+    if ((rc = bind(ctx))) return rc;
+    if (!out_dev) return fail(MI355_E_INVALID, "out_dev is null");
+    if (n && !packed_dev) return fail(MI355_E_INVALID, "null device pointer");
+    if (((uintptr_t)packed_dev & 15) || ((uintptr_t)mask_dev & 3)) return fail(MI355_E_INVALID, "packed_dev must be 16-byte, mask_dev 4-byte aligned");
+    AggArgs a;
+    a.packed = (const uint8_t *)packed_dev;
+    a.n = n;
+    a.mask = (const uint8_t *)mask_dev;
+    a.out = (unsigned long long *)out_dev;
+    if (n == 0) {
+        hipLaunchKernelGGL(aggregate_init_kernel, dim3(1), dim3(1), 0, ctx->stream, a.out);
+    } else if (!launch_aggregate_width(c, a, ctx->num_cus, ctx->stream)) {
+        return fail(MI355_E_INVALID, "width %u", c);
+    }
     HIP_TRY(hipGetLastError());
     return MI355_OK;
 }

@@ -282,6 +282,15 @@ class ScanEngine:
                                      out.data_ptr()))
         return out
 
+    def aggregate(self, col: PackedColumn, mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """-> int64[4] device tensor (sum, count, min, max) of the column's values over the rows of `mask` (a result bitmap;
+        None = every row): one pass over the column, nothing decoded to memory.  count = 0: min is -1 (UINT64_MAX)."""
+        if out is None:
+            out = torch.empty(4, dtype=torch.int64, device=self._dev)
+        check(lib().mi355_aggregate_dev(self._ctx, col.data.data_ptr(), col.n, col.c, mask.data_ptr() if mask is not None else None,
+                                        out.data_ptr()))
+        return out
+
     # ---- shared scans (src/simd_scan_shared.cpp, src/simd_scan_shared_linear.cpp) -----------------
     def shared_scan(self, keys: Sequence[int], col: PackedColumn, layout: str = "per_predicate",
                     out: Optional[torch.Tensor] = None, hits: Optional[torch.Tensor] = None):

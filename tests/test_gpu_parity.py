@@ -507,6 +507,42 @@ def test_gather_values_at_row_ids(O, eng, c):
     assert np.array_equal(taken[:k].cpu().numpy(), vals2[expect_rows].astype(np.int32))
 
 
+@pytest.mark.parametrize("c", [1, 2, 5, 7, 9, 12, 16, 17, 24, 25, 31, 32])
+def test_aggregate_under_a_bitmap(O, eng, c):
+    """mi355_aggregate_dev: sum / count / min / max of a column over the rows of a bitmap (or all rows) in one pass --
+    against numpy on the oracle's values; ragged columns, an empty selection, the widths on both sides of the 32 / 64-bit
+    partial sums (c = 24 / 25), 32-bit values"""
+    import torch
+
+    rng = np.random.default_rng(4400 + c)
+    for n in (8192 * 6 + 4099, 8192 * 2, 777, 1):
+        vals, col = make_column(O, eng, n, c, 8800 + c + n)
+        v = vals.astype(np.uint64)
+        got = eng.aggregate(col).cpu().numpy().view(np.uint64)
+        assert got.tolist() == [int(v.sum()), n, int(v.min()), int(v.max())], (c, n)
+        # a mask from a predicate on another column
+        vals2, col2 = make_column(O, eng, n, 9, 8900 + c + n)
+        a = int(rng.integers(0, 512))
+        mask, hits = eng.scan_where("<", a, col2)
+        sel = vals2 < a
+        got = eng.aggregate(col, mask=mask).cpu().numpy().view(np.uint64)
+        if sel.any():
+            assert got.tolist() == [int(v[sel].sum()), int(sel.sum()), int(v[sel].min()), int(v[sel].max())], (c, n, a)
+        else:
+            assert got.tolist() == [0, 0, 2 ** 64 - 1, 0], (c, n, a)
+        empty = torch.zeros_like(mask)
+        assert eng.aggregate(col, mask=empty).cpu().numpy().view(np.uint64).tolist() == [0, 0, 2 ** 64 - 1, 0]
+    # the whole pipeline on the device: predicate on one column -> sum of another, 2e7 rows (sums beyond 32 bits)
+    n = 20_000_000 + 77
+    col_a = eng.generate("mod", n, 9, 7)
+    col_b = eng.generate("index", n, c)
+    mask, hits = eng.scan(3, col_a)
+    rows = np.arange(3, n, 7, dtype=np.uint64)
+    vb = rows & np.uint64((1 << c) - 1)
+    got = eng.aggregate(col_b, mask=mask).cpu().numpy().view(np.uint64)
+    assert got.tolist() == [int(vb.sum()), rows.shape[0], int(vb.min()), int(vb.max())], c
+
+
 def test_out_of_range_keys_never_match(O, eng):
     """SURVEY 8c hazard 5: keys 515, 1027, 65539, -1 on a 9-bit column -> no hits, zero bitmap."""
     import torch
@@ -1279,6 +1315,9 @@ def test_fuzz_round2_entry_points(O, eng, seed):
         assert int(cnt.item()) == rows.shape[0], (seed, c, n, a, b)
         k = min(cap, rows.shape[0])
         assert np.array_equal(ids[:k].cpu().numpy(), rows[:k] + first), (seed, c, n, a, b, cap)
+        agg = eng.aggregate(col2, mask=bm1).cpu().numpy().view(np.uint64).tolist()
+        u2 = vals2.astype(np.uint64)
+        assert agg == ([int(u2[p1].sum()), int(p1.sum()), int(u2[p1].min()), int(u2[p1].max())] if p1.any() else [0, 0, 2 ** 64 - 1, 0]), (seed, c, n)
         if k:
             taken = eng.gather(col2, ids[:k], k, first_row=first)
             assert np.array_equal(taken[:k].cpu().numpy().view(np.uint32), vals2[rows[:k]]), (seed, c, n)
