@@ -109,6 +109,25 @@ int main(int argc, char **argv)
         OK(mi355_dev_free(ctx, taken_dev));
     }
 
+    // aggregates of column 2 over the rows of the mask (v1 <= 2), and over all rows
+    {
+        uint64_t agg[4], sum = 0, cnt = 0, mn = ~0ull, mx = 0;
+        OK(mi355_aggregate_dev(ctx, col2, n, c, mask_dev, hits_dev));
+        OK(mi355_dev_download(ctx, agg, hits_dev, sizeof agg));
+        for (uint64_t i = 0; i < n; i++)
+            if (v1(i) <= 2) {
+                sum += v2(i), cnt++;
+                if (v2(i) < mn) mn = v2(i);
+                if (v2(i) > mx) mx = v2(i);
+            }
+        REQUIRE(agg[0] == sum && agg[1] == cnt && agg[2] == mn && agg[3] == mx);
+        OK(mi355_aggregate_dev(ctx, col2, n, c, nullptr, hits_dev));
+        OK(mi355_dev_download(ctx, agg, hits_dev, sizeof agg));
+        sum = 0;
+        for (uint64_t i = 0; i < n; i++) sum += v2(i);
+        REQUIRE(agg[0] == sum && agg[1] == n && agg[2] == 0 && agg[3] == m2 - 1);
+    }
+
     // shared scans: 2 keys (compare kernel), 5 keys (one-pass LUT, packed rows), 37 keys (32 keys per lookup), both layouts
     for (unsigned P : {2u, 5u, 37u}) {
         std::vector<int32_t> keys(P);
