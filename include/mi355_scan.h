@@ -263,6 +263,12 @@ MI355_API int mi355_gather_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t 
 MI355_API int mi355_aggregate_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const void *mask_dev,
                                   uint64_t *out_dev);
 
+/* Histogram: counts_dev[v] = number of rows (of the bitmap mask_dev, or all rows when NULL) whose value is v, for every
+ * v in [0, 2^c) -- `SELECT v, count(*) ... GROUP BY v` over a dictionary-coded column in one pass.  c <= 14 (the counters
+ * live in LDS); counts_dev: 2^c uint64, overwritten.  Asynchronous on the context's stream. */
+MI355_API int mi355_histogram_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const void *mask_dev,
+                                  uint64_t *counts_dev);
+
 /* ---- row-range sharding helper (one process per GPU): rank's rows [first, first+count) of an n-row
  * column split over `world` ranks at multiples of 8192 rows, so every shard's packed slice starts 16-byte aligned on
  * a whole value and its bitmap slice on a whole byte.  Pure arithmetic, no device needed. */

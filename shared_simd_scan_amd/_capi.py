@@ -62,6 +62,7 @@ SYMBOLS = [
     ("mi355_bitmap_to_rowids_dev", _int, [_vp, _vp, _u64, _u64, _vp, _u64, _vp]),
     ("mi355_gather_dev", _int, [_vp, _vp, _u64, C.c_uint, _u64, _vp, _vp, _u64, _vp]),
     ("mi355_aggregate_dev", _int, [_vp, _vp, _u64, C.c_uint, _vp, _vp]),
+    ("mi355_histogram_dev", _int, [_vp, _vp, _u64, C.c_uint, _vp, _vp]),
     ("mi355_comm_get_unique_id", _int, [_vp]),
     ("mi355_comm_create", _int, [_vp, _int, _int, _vp, C.POINTER(_vp)]),
     ("mi355_comm_destroy", _int, [_vp]),

@@ -13,6 +13,7 @@
 #include "extras/gather.hpp"
 #include "kernels.hpp"
 #include "extras/aggregate.hpp"
+#include "extras/histogram.hpp"
 
 using namespace mi355;
 
@@ -935,6 +936,29 @@ int mi355_aggregate_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsi
     } else if (!launch_aggregate_width(c, a, ctx->num_cus, ctx->stream)) {
         return fail(MI355_E_INVALID, "width %u", c);
     }
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+}
+
+int mi355_histogram_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, unsigned c, const void *mask_dev, uint64_t *counts_dev)
+{
+    int rc = resolve(ctx);
+    if (rc) return rc;
+    CtxLock lk(ctx->mu);
+    if ((rc = check_width(c))) return rc;
+    if (c > (unsigned)kHistogramMaxBits) return fail(MI355_E_INVALID, "histogram: widths up to %d bits (2^c counters in LDS), got %u", kHistogramMaxBits, c);
+    if ((rc = bind(ctx))) return rc;
+    if (!counts_dev) return fail(MI355_E_INVALID, "counts_dev is null");
+    if (n && !packed_dev) return fail(MI355_E_INVALID, "null device pointer");
+    if (((uintptr_t)packed_dev & 15) || ((uintptr_t)mask_dev & 3)) return fail(MI355_E_INVALID, "packed_dev must be 16-byte, mask_dev 4-byte aligned");
+    HIP_TRY(hipMemsetAsync(counts_dev, 0, sizeof(uint64_t) << c, ctx->stream));
+    if (n == 0) return MI355_OK;
+    HistArgs a;
+    a.packed = (const uint8_t *)packed_dev;
+    a.n = n;
+    a.mask = (const uint8_t *)mask_dev;
+    a.out = (unsigned long long *)counts_dev;
+    if (!launch_histogram_width(c, a, ctx->num_cus, ctx->stream)) return fail(MI355_E_INVALID, "width %u", c);
     HIP_TRY(hipGetLastError());
     return MI355_OK;
 }

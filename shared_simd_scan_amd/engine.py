@@ -291,6 +291,15 @@ class ScanEngine:
                                         out.data_ptr()))
         return out
 
+    def histogram(self, col: PackedColumn, mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """-> int64[2^c] device tensor: how often each value occurs among the rows of `mask` (None = all rows); c <= 14"""
+        if out is None:
+            out = torch.empty(1 << col.c, dtype=torch.int64, device=self._dev)
+        assert out.numel() >= (1 << col.c) and out.dtype == torch.int64
+        check(lib().mi355_histogram_dev(self._ctx, col.data.data_ptr(), col.n, col.c, mask.data_ptr() if mask is not None else None,
+                                        out.data_ptr()))
+        return out
+
     # ---- shared scans (src/simd_scan_shared.cpp, src/simd_scan_shared_linear.cpp) -----------------
     def shared_scan(self, keys: Sequence[int], col: PackedColumn, layout: str = "per_predicate",
                     out: Optional[torch.Tensor] = None, hits: Optional[torch.Tensor] = None):

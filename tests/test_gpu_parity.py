@@ -543,6 +543,31 @@ def test_aggregate_under_a_bitmap(O, eng, c):
     assert got.tolist() == [int(vb.sum()), rows.shape[0], int(vb.min()), int(vb.max())], c
 
 
+@pytest.mark.parametrize("c", [1, 3, 7, 9, 12, 13, 14])
+def test_histogram_under_a_bitmap(O, eng, c):
+    """mi355_histogram_dev: per-value row counts (GROUP BY over a dictionary-coded column), all rows or the rows of a bitmap,
+    against numpy.bincount; ragged columns, skewed data (every lane adding to the same few counters), widths above 14 refused"""
+    import torch
+
+    for n in (8192 * 9 + 4099, 8192 * 4, 77):
+        vals, col = make_column(O, eng, n, c, 6600 + c + n)
+        got = eng.histogram(col).cpu().numpy()
+        assert np.array_equal(got, np.bincount(vals, minlength=1 << c)), (c, n)
+        vals2, col2 = make_column(O, eng, n, 9, 6700 + c + n)
+        mask, _ = eng.scan_where(">=", 300, col2)
+        got = eng.histogram(col, mask=mask).cpu().numpy()
+        assert np.array_equal(got, np.bincount(vals[vals2 >= 300], minlength=1 << c)), (c, n)
+    n = 30_000_000 + 5
+    col = eng.generate("mod", n, c, 3 if c > 1 else 2)  # three hot counters
+    m = 3 if c > 1 else 2
+    want = np.zeros(1 << c, dtype=np.int64)
+    for k in range(m):
+        want[k] = (n - 1 - k) // m + 1
+    assert np.array_equal(eng.histogram(col).cpu().numpy(), want)
+    with pytest.raises(Exception):
+        eng.histogram(eng.generate("mod", 1000, 15, 5), out=torch.empty(1 << 15, dtype=torch.int64, device="cuda"))
+
+
 def test_out_of_range_keys_never_match(O, eng):
     """SURVEY 8c hazard 5: keys 515, 1027, 65539, -1 on a 9-bit column -> no hits, zero bitmap."""
     import torch
@@ -1315,6 +1340,8 @@ def test_fuzz_round2_entry_points(O, eng, seed):
         assert int(cnt.item()) == rows.shape[0], (seed, c, n, a, b)
         k = min(cap, rows.shape[0])
         assert np.array_equal(ids[:k].cpu().numpy(), rows[:k] + first), (seed, c, n, a, b, cap)
+        if c <= 14:
+            assert np.array_equal(eng.histogram(col2, mask=bm1).cpu().numpy(), np.bincount(vals2[p1], minlength=1 << c)), (seed, c, n)
         agg = eng.aggregate(col2, mask=bm1).cpu().numpy().view(np.uint64).tolist()
         u2 = vals2.astype(np.uint64)
         assert agg == ([int(u2[p1].sum()), int(p1.sum()), int(u2[p1].min()), int(u2[p1].max())] if p1.any() else [0, 0, 2 ** 64 - 1, 0]), (seed, c, n)

@@ -61,6 +61,9 @@ def main():
         report(f"scan_in P={P}", timed(lambda: eng.scan_in(keys, col, bitmap=out, hits=h1)), pk + nb)
     report("aggregate: sum / count / min / max of the column", timed(lambda: eng.aggregate(col)), pk, "one pass, nothing decoded to memory")
     report("aggregate under a bitmap (WHERE earlier predicate)", timed(lambda: eng.aggregate(col, mask=bm_a)), pk + nb)
+    if c <= 14:
+        report("histogram: rows per value (GROUP BY)", timed(lambda: eng.histogram(col)), pk, "2^c counters in LDS, one LDS atomic per value")
+        report("histogram under a bitmap", timed(lambda: eng.histogram(col, mask=bm_a)), pk + nb)
     report("bitmap_combine AND (+popcount)", timed(lambda: eng.bitmap_combine("and", bm_a, bm_b, n, out=out)), 3 * nb)
     report("bitmap_count", timed(lambda: eng.bitmap_count(bm_a, n)), nb)
     # fused consumers: what leaves out the bitmap round trip through HBM
