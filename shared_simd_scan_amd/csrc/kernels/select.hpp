@@ -279,20 +279,50 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
                 const uint32_t count = npass == 1 ? total : (h ? total - first_half : first_half);
                 if (count == 0) continue;
                 if (npass == 1 || (lane >> 5) == h) {
-                    uint32_t p = incl - cnt - base;
+                    // the lane's WORDS words side by side: one loop of max-popcount iterations with WORDS independent
+                    // ctz / clear / ds_write chains in each, instead of sum-of-popcounts iterations of one dependent chain
+                    // (one wave per SIMD: only instruction-level parallelism hides the latencies here)
+                    uint32_t pw[WORDS], ww[WORDS];
+                    uint32_t p = incl - cnt - base, any = 0;
 #pragma unroll
                     for (int j = 0; j < WORDS; j++) {
-                        uint32_t w = b[j];
-                        const uint32_t off0 = lane * VPL + 32 * j;
-                        while (w) {
-                            const int i = __builtin_ctz(w);
-                            w &= w - 1;
-                            st[p++] = (uint16_t)(off0 + i);
+                        ww[j] = b[j];
+                        pw[j] = p;
+                        p += __builtin_popcount(b[j]);
+                        any |= b[j];
+                    }
+                    while (any) {
+                        any = 0;
+#pragma unroll
+                        for (int j = 0; j < WORDS; j++) {
+                            if (ww[j]) {
+                                const int i = __builtin_ctz(ww[j]);
+                                ww[j] &= ww[j] - 1;
+                                st[pw[j]++] = (uint16_t)(lane * VPL + 32 * j + i);
+                            }
+                            any |= ww[j];
                         }
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's stage writes are done (LDS is in order per wave)
-                for (uint32_t i = lane; i < count; i += 64) {
+                // copy-out, four ids per lane and round: the LDS reads of a round are issued together
+                uint32_t i = lane;
+                for (; i + 192 < count; i += 256) {
+                    const uint32_t s0 = st[i], s1 = st[i + 64], s2 = st[i + 128], s3 = st[i + 192];
+                    const uint64_t o = out + base + i;
+                    if (o + 192 < a.capacity) {
+                        a.rowids[o] = row0 + s0;
+                        a.rowids[o + 64] = row0 + s1;
+                        a.rowids[o + 128] = row0 + s2;
+                        a.rowids[o + 192] = row0 + s3;
+                    } else {
+                        if (o < a.capacity) a.rowids[o] = row0 + s0;
+                        if (o + 64 < a.capacity) a.rowids[o + 64] = row0 + s1;
+                        if (o + 128 < a.capacity) a.rowids[o + 128] = row0 + s2;
+                        if (o + 192 < a.capacity) a.rowids[o + 192] = row0 + s3;
+                    }
+                }
+                for (; i < count; i += 64) {
                     const uint64_t o = out + base + i;
                     if (o < a.capacity) a.rowids[o] = row0 + st[i];
                 }

@@ -78,7 +78,11 @@ struct ScanArgs {
     uint32_t invert;           // kModeEq / kModeRange: 0, or 0xffffffff to negate the predicate (!=, NOT BETWEEN)
     uint32_t mask_op;          // how and_mask is combined: 0 result & mask, 1 result | mask, 2 result ^ mask, 3 mask & ~result
                                // (kModeEq / kModeRange; in_kernel: AND only)
-    uint32_t flags;            // experiment switches (tuning aids): bit 0 = shared_wide_kernel drains its stores every tile
+    uint32_t flags;            // A/B switches (option "kernel_flags", DESIGN.md "A/B switches"; they never change a result):
+                               // shared scans: 1 shared_wide_kernel drains its stores every tile; 2 per-group kernels instead of
+                               // shared_wide2 / shared_linear; 4 rotate the 32-key rounds; 8 per-tile hit-count reductions; 16 P = 16
+                               // linear one row per piece; 32 P = 2 on the LUT kernel; 64 compare chain; 128 shared_linear_kernel
+                               // whatever the width.  select_kernel (bits 9, 10 of the option arrive here as 2, 4): timing ablations
     const uint8_t *packed2;    // scan2_kernel: the second column (same width, same n)
     uint32_t key2[2];          // scan2_kernel: second predicate as (lo, hi - lo)
     uint32_t invert2;          // scan2_kernel: negation word of the second predicate
