@@ -253,6 +253,25 @@ class ShardedColumn:
         ex.gather_at(local, sizes, offsets, dst, out.view(torch.uint8) if out is not None else None, engine=eng)
         return out, sum(counts)
 
+    def aggregate(self, mask: Optional[torch.Tensor] = None):
+        """(sum, count, min, max) of the whole column over the rows of `mask` (this rank's slice of a result bitmap; None =
+        every row), as Python ints on every rank: each rank's one-pass aggregate, then ONE all-reduce -- sums add, and the
+        per-rank minima / maxima travel in a one-hot vector (min is None when no row counts)."""
+        eng, ex, dev = self.engine, self.exchange, self._device()
+        if self.rows:
+            local = eng.aggregate(self.col, mask=mask).to(dev)
+        else:
+            local = torch.tensor([0, 0, -1, 0], dtype=torch.int64, device=dev)
+        vec = torch.zeros(2 + 2 * self.world, dtype=torch.int64, device=dev)
+        vec[0:2] = local[0:2]
+        # (min = UINT64_MAX = -1 when the rank counted nothing: sent as -1, skipped below)
+        vec[2 + 2 * self.rank] = local[2]
+        vec[3 + 2 * self.rank] = local[3]
+        tot = ex.sum_hits(vec, engine=eng).cpu().tolist()
+        mins = [tot[2 + 2 * r] for r in range(self.world) if tot[2 + 2 * r] >= 0]
+        maxs = [tot[3 + 2 * r] for r in range(self.world)]
+        return int(tot[0]), int(tot[1]), (min(mins) if mins and tot[1] else None), (max(maxs) if tot[1] else 0)
+
     def scan_pipelined(self, key: int, dst: int = 0, chunks: int = 4):
         """Same result as scan().  The shard is scanned in `chunks` row ranges (boundaries at multiples of SHARD_ALIGN)
         and the gather of range i is enqueued as soon as its scan is: with the RCCL exchange on a side stream the

@@ -79,6 +79,17 @@ class OracleEngine:
         return ids, torch.tensor([rows.shape[0]], dtype=torch.int64)
 
 
+    def aggregate(self, col, mask=None):
+        packed, n, c = col
+        v = self.O.decompress(packed, n, c).astype(np.uint64) if n else np.zeros(0, dtype=np.uint64)
+        if mask is not None:
+            bits = np.unpackbits(mask.numpy()[: (n + 7) // 8], bitorder="little")[:n].astype(bool)
+            v = v[bits]
+        if v.shape[0] == 0:
+            return torch.tensor([0, 0, -1, 0], dtype=torch.int64)
+        return torch.tensor([int(v.sum()), int(v.shape[0]), int(v.min()), int(v.max())], dtype=torch.int64)
+
+
 def worker(rank, world, port, n, c, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -96,6 +107,12 @@ def worker(rank, world, port, n, c, q):
         full_r, hits_r = sc.scan_range(lo, hi, dst=0)
         full_p, hits_p = sc.scan_pipelined(key, dst=0, chunks=3)  # chunked scan + asynchronous gathers: same result
         ids, nids = sc.select("between", lo, dst=0, b=hi)           # global row ids on the root, the count everywhere
+        local_bm, _ = sc.engine.scan_range(lo, hi, sc.col)
+        agg = sc.aggregate(mask=local_bm)                           # aggregates over the predicate's rows, on every rank
+        vals_all = O.gen_values("splitmix", n, c, 42).astype(np.uint64)
+        sel_all = vals_all[(vals_all >= lo) & (vals_all <= hi)]
+        assert agg == ((int(sel_all.sum()), int(sel_all.shape[0]), int(sel_all.min()), int(sel_all.max())) if sel_all.shape[0] else (0, 0, None, 0)), agg
+        assert sc.aggregate()[:2] == (int(vals_all.sum()), n)
         if rank == 0:
             vals = O.gen_values("splitmix", n, c, 42)
             want_ids = np.nonzero((vals >= lo) & (vals <= hi))[0].astype(np.int64)
@@ -174,6 +191,11 @@ def gpu_worker(rank, world, port, n, c, base_row, q):
         full_r, hits_r = sc.scan_range(lo, hi, dst=0)
         full_p, hits_p = sc.scan_pipelined(key, dst=0, chunks=3)
         ids, nids = sc.select("between", lo, dst=0, b=hi)  # fused selection per shard, global ids gathered on the root
+        local_bm, _ = eng.scan_range(lo, hi, sc.col) if sc.rows else (None, None)
+        agg = sc.aggregate(mask=local_bm)
+        vals_all = O.gen_values("splitmix", n, c, 42, first=base_row).astype(np.uint64)
+        sel_all = vals_all[(vals_all >= lo) & (vals_all <= hi)]
+        assert agg == ((int(sel_all.sum()), int(sel_all.shape[0]), int(sel_all.min()), int(sel_all.max())) if sel_all.shape[0] else (0, 0, None, 0)), agg
         if rank == 0:
             vals = O.gen_values("splitmix", n, c, 42, first=base_row)
             want_ids = np.nonzero((vals >= lo) & (vals <= hi))[0].astype(np.int64) + base_row
