@@ -17,6 +17,8 @@
 //   * BITS_NEEDED may be defined before including this header (the reference hard-wires 9).
 #pragma once
 
+#include <bitset>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
@@ -50,8 +52,17 @@ constexpr size_t scan_output_buffer_size(size_t input_array_size)
     return input_array_size / 8 + (input_array_size % 8 != 0) + 32;
 }
 
-// src/util.hpp:10-13, src/util.cpp:51-58
+// ---- the reference's L0 utilities (src/util.hpp:5-25: next_multiple, get_bit, dump_*, POPCNT) ---------------------
+// They are NOT part of the scan path and stay the reference's: its header pulls them in with `#include "util.hpp"`
+// (src/simd_scan.hpp:10) and its callers include that file themselves, before (test/simd_scan_tests.cpp:3-4) or after
+// (src/main.cpp:7-8, src/benchmark.cpp:2-3) this header.  So inside the reference's tree this header does exactly what
+// the reference's does -- the one util.hpp on the include path, defined once, src/util.cpp linked as before.  Only a
+// build WITHOUT the reference's tree (no util.hpp reachable) gets the inline equivalents below.
+#if __has_include("util.hpp")
+#include "util.hpp"
+#else
 constexpr int next_multiple(int number, int multiple) { return ((number + multiple - 1) / multiple) * multiple; }
+// src/util.cpp:51-58
 inline bool get_bit(std::vector<uint8_t> const &vector, size_t absolute_index)
 {
     return (vector[absolute_index / 8] & (1 << (absolute_index % 8))) > 0;
@@ -62,6 +73,10 @@ inline bool get_bit(std::vector<uint32_t> const &vector, size_t absolute_index)
     const uint8_t element = (uint8_t)vector[absolute_index / 8];
     return (element & (1 << (absolute_index % 8))) > 0;
 }
+#ifndef POPCNT
+#define POPCNT(i) __builtin_popcount(i) // src/util.hpp:17-25
+#endif
+#endif
 
 namespace mi355_dropin {
 inline void check(int rc, const char *what)

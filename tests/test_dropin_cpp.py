@@ -112,3 +112,34 @@ def test_cli_mirrors_reference_bench_harness(args):
     assert len(rows) >= 1 and all(ms > 0 for _, ms in rows)
     n = int(args[0]) * (1 << 20) * 8 // 9
     assert f"compressed input: {n} (" in res.stdout
+
+
+# ---- the reference's OWN callers, built unchanged against the drop-in by oracle/Makefile (build container only; the
+# binaries travel in oracle/_ref like the compiled reference itself), RUN here on the engine ---------------------------
+REF_UNIT = os.path.join(ROOT, "oracle", "_ref", "ref_unit_tests_dropin")
+REF_BENCH = os.path.join(ROOT, "oracle", "_ref", "ref_shared_simd_scan_dropin")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_UNIT), reason="oracle/_ref/ref_unit_tests_dropin not built (no /root/reference)")
+def test_reference_own_catch_tests_run_on_the_engine():
+    """test/simd_scan_tests.cpp + test/util_tests.cpp of the reference, byte for byte, linked against libmi355scan.so:
+    its 6 test cases / 1175 assertions on the GPU path"""
+    res = subprocess.run([REF_UNIT], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-4000:] + res.stderr[-2000:]
+    assert "All tests passed (1175 assertions in 6 test cases)" in res.stdout, res.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BENCH), reason="oracle/_ref/ref_shared_simd_scan_dropin not built")
+@pytest.mark.parametrize("args", [["40", "2", "decompression"], ["40", "2", "scan"], ["40", "2", "sharedscan", "8"],
+                                  ["11", "1", "sharedscan", "3"]])
+def test_reference_own_benchmark_harness_runs_on_the_engine(args):
+    """src/main.cpp + src/benchmark.cpp of the reference, unchanged, on the engine: every variant it times goes through
+    include/simd_scan.hpp, and its own self-checks (`first mismatch at index`, src/benchmark.cpp:38-49,110-121) stay
+    silent"""
+    res = subprocess.run([REF_BENCH] + args, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-4000:] + res.stderr[-2000:]
+    assert "mismatch" not in res.stdout, res.stdout[-4000:]
+    rows = parse_output(res.stdout)
+    assert len(rows) >= 4, res.stdout
