@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -43,13 +44,26 @@ Rccl *rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char *nm : names) {
+        // MI355_RCCL_LIB names the one library to use (a site's own build; also how the tests force the "no librccl"
+        // case); otherwise the usual names, the process's already-loaded copy first
+        const char *forced = getenv("MI355_RCCL_LIB");
+        const char *defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        std::string last;
+        auto try_open = [&](const char *nm) {
             r.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-            if (r.handle) break;
-        }
+            if (!r.handle) {
+                const char *e = dlerror(); // ONE call: dlerror() clears the message it returns
+                last = e ? e : "?";
+            }
+            return r.handle != nullptr;
+        };
+        if (forced && *forced)
+            try_open(forced);
+        else
+            for (const char *nm : defaults)
+                if (try_open(nm)) break;
         if (!r.handle) {
-            r.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+            r.why = std::string("librccl not found: ") + last;
             return;
         }
         bool ok = true;
@@ -160,7 +174,21 @@ int mi355_gather_bitmaps_at_dev(mi355_ctx *ctx, mi355_comm *comm, const void *lo
     uint64_t total = 0;
     for (int r = 0; r < comm->world; r++) total += bytes_per_rank[r];
     if (comm->rank == root && total && !out_dev) return fail(MI355_E_INVALID, "out_dev is null on the root");
+    if (offset_per_rank) {
+        // the slices land at caller-chosen offsets of ONE buffer: two that overlap would race on the root.  Checked on
+        // EVERY rank (all ranks pass the same arrays), so a bad layout fails everywhere instead of leaving peers in a send
+        for (int a = 0; a < comm->world; a++)
+            for (int b = a + 1; b < comm->world; b++) {
+                const uint64_t a0 = offset_per_rank[a], a1 = a0 + bytes_per_rank[a];
+                const uint64_t b0 = offset_per_rank[b], b1 = b0 + bytes_per_rank[b];
+                if (a1 < a0 || b1 < b0) return fail(MI355_E_INVALID, "offset + bytes overflows");
+                if (bytes_per_rank[a] && bytes_per_rank[b] && a0 < b1 && b0 < a1)
+                    return fail(MI355_E_INVALID, "slices of ranks %d and %d overlap: [%llu, %llu) and [%llu, %llu)", a, b,
+                                (unsigned long long)a0, (unsigned long long)a1, (unsigned long long)b0, (unsigned long long)b1);
+            }
+    }
     Rccl *R = rccl();
+    if (!R->handle) return fail(MI355_E_COMM, "%s", R->why.c_str());
     CtxLock lk(ctx->mu);
     if ((rc = bind(ctx))) return rc;
     if (comm->rank != root) {

@@ -11,25 +11,26 @@
 //   one 32-bit bitmap word per 32 values in the lane, written back as 16 B / lane (1 KiB / wave).
 //
 // Kernels (one header per family under kernels/):
-//   scan_kernel            equality / range scan (+ negation, + AND with an earlier bitmap), one bitmap; widths <= 7
-//                          evaluate several values per LDS table lookup instead of the compare chain
+//   scan_burst_kernel      equality / range scan (+ negation, + AND / OR / XOR / ANDNOT with an earlier bitmap, count-only),
+//                          one bitmap; widths <= 7 evaluate several values per LDS table lookup instead of the compare chain
+//   scan2_kernel           predicates over two columns of one width in one launch
 //   shared_lut_kernel      shared multi-predicate scan (P <= 8, and linear rows below 192 keys) through byte-entry LDS
 //                          lookup tables + 8x8 bit transposes
-//   shared_wide_kernel     shared scan for P > 8: dword-entry tables, 32 predicates per lookup
+//   shared_pair_kernel     two keys by compares
+//   shared_wide_kernel, shared_wide2_kernel, shared_linear_kernel
+//                          shared scan for P > 8: dword-entry tables, 32 predicates per lookup
 //   shared_general_kernel  shared scan by compare chain, for key counts whose tables do not fit in LDS
 //   in_kernel              IN-list scan (one bitmap for a key set)
 //   select_kernel          predicate -> ascending row ids in one launch (decoupled look-back over chunk counts), no bitmap
 //   decompress_kernel      packed -> int32, lane per value
 //   pack_kernel            packer and synthetic column generators
 //   bitmap_kernel, rowid_* bitmap combine / count, selection vector
-// ABL / DEPTH template knobs of scan_kernel exist for tools/tune_scan.hip (ablations, diagnostics, experiments);
-// the shipped dispatch (width_group.hip) always uses ABL = 0, DEPTH = 1.
+// Only kernels libmi355scan.so launches live here; ablation / experiment kernels are under tools/ (scan_kernel_r1.hpp).
 //
 // What this replaces in the reference (RRr89/Shared_SIMD_Scan): the pshufb byte-gather + pmulld /
 // psrld shift + pcmpeqd + movmskps chains of src/simd_scan.cpp:103-306, src/simd_scan_shared.cpp:34-151,
 // src/simd_scan_shared_linear.cpp:9-62 and src/simd_scan_decompression.cpp:237-470.  No MFMA: this is
 // integer/bit work bound by HBM bandwidth.
-#pragma once
 #pragma once
 
 #include "kernels/tile.hpp"

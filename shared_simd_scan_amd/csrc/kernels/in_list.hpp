@@ -9,7 +9,7 @@ namespace mi355 {
 // One result bitmap for a set of keys (the OR-reduction of a shared scan).
 //   C <= 16: the set is a 2^C-bit bitset in LDS (<= 8 KiB) built by the block; one byte lookup + bit extract per value.
 //   C  > 16: compare chain over the key list (device array, padded to 8): O(P) half-rate compares per value.
-// Same tile / DMA / deferred-store skeleton as scan_kernel (VPL from scan_vpl(C, kModeEq)); and_mask / invert apply.
+// Same tile / DMA / deferred-store skeleton as scan_burst_kernel with K = 1 (VPL from scan_vpl(C, kModeEq)); and_mask / invert apply.
 template <int C, int AUX_, int VPL>
 __global__ __launch_bounds__(kBlockThreads) void in_kernel(ScanArgs a)
 {

@@ -408,7 +408,7 @@ template <int P, int GROUPS, int NRES> __device__ __forceinline__ void store_lin
 
 // LAYOUT 0: per-predicate bitmaps at out + k*out_stride; 1: linear (byte of 8-value group g and key k at
 // g*P + k, src/simd_scan_shared_linear.cpp:57).  MULTI false: P <= 8, one pass, stores deferred by one tile
-// (as in scan_kernel); true: ceil(P/8) passes per tile, stored pass by pass.
+// (as in the equality scan); true: ceil(P/8) passes per tile, stored pass by pass.
 template <int C, int AUX_, int VPL, int LAYOUT, bool MULTI>
 __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
 {

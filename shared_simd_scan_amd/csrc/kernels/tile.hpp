@@ -91,7 +91,7 @@ struct ScanArgs {
     uint64_t capacity;         // select_kernel: at most this many ids are written
     uint64_t first_row;        // select_kernel: global row index of row 0
 };
-// `out` may be null in scan_kernel / scan2_kernel: count-only scan (hits without a bitmap).
+// `out` may be null in scan_burst_kernel / scan2_kernel: count-only scan (hits without a bitmap).
 
 // ---- DMA: HBM -> LDS ---------------------------------------------------------------------------
 // One wave-instruction moves 64 x 16 B; the LDS destination is wave-uniform base + lane*16, the

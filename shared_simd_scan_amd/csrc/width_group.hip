@@ -102,7 +102,7 @@ template <int C, int MODE> void launch_scan(const LaunchReq &r)
         else
             hipLaunchKernelGGL((scan_burst_kernel<C, MODE, 2, VPL, K>), grid, dim3(kBlockThreads), 0, r.stream, r.scan);
     };
-    // "scan_burst" option: 0 = the width's default, 1 = one tile per burst (scan_kernel's shape; A/B)
+    // "scan_burst" option: 0 = the width's default, 1 = one tile per burst (A/B)
     if (burst_k(C) > 1 && r.scan_burst != 1)
         go(std::integral_constant<int, burst_k(C)>{});
     else

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../shared_simd_scan_amd/csrc/kernels.hpp"
+#include "scan_kernel_r1.hpp"
 
 using namespace mi355;
 
