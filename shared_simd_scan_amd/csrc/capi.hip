@@ -683,15 +683,19 @@ int mi355_scan_select_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, un
     const uint64_t tile_values = 64 * (uint64_t)scan_vpl((int)c, kModeRange);
     const uint64_t ntiles = (n + tile_values - 1) / tile_values;
     const uint64_t nchunks = (ntiles + select_tiles((int)c) - 1) / select_tiles((int)c);
-    if (ctx->rowid_ws_entries < nchunks) {
+    // + the chunk-ticket counter on its own line behind them (select_state_words); the same memset zeroes both
+    const uint64_t nwords = select_state_words(nchunks);
+    if (ctx->rowid_ws_entries < nwords) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->rowid_ws) HIP_TRY(hipFree(ctx->rowid_ws));
         ctx->rowid_ws = nullptr;
         ctx->rowid_ws_entries = 0;
-        HIP_TRY(hipMalloc((void **)&ctx->rowid_ws, nchunks * sizeof(unsigned long long)));
-        ctx->rowid_ws_entries = nchunks;
+        HIP_TRY(hipMalloc((void **)&ctx->rowid_ws, nwords * sizeof(unsigned long long)));
+        ctx->rowid_ws_entries = nwords;
     }
-    HIP_TRY(hipMemsetAsync(ctx->rowid_ws, 0, nchunks * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->rowid_ws, 0, nwords * sizeof(unsigned long long), ctx->stream));
+    // the count is written by atomic max (the last chunk's total, or ~0 from a wave that gave up): start it at 0
+    HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(uint64_t), ctx->stream));
     LaunchReq r{};
     r.op = kOpSelect;
     r.c = c;

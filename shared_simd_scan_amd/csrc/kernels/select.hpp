@@ -15,7 +15,7 @@ namespace mi355 {
 // earlier chunks: a decoupled look-back over per-chunk state words supplies it inside the launch.
 //
 //   state[q] = { status : 2, value : 62 }   status 0 = nothing yet, 1 = value is chunk q's own count (aggregate),
-//                                           2 = value is the count of chunks 0..q (inclusive prefix)
+//                                           2 = value is the count of chunks 0..q (inclusive prefix), 3 = poisoned
 //   wave of chunk q:  publish {1, count_q}; read the state of the 1024 chunks in front of it in one poll (16 per
 //   lane, nearest first), add aggregates until a chunk that already knows its inclusive prefix; publish
 //   {2, prefix + count_q}.  The persistent grid has ~1024 waves in flight, each on one chunk, so one poll normally
@@ -26,10 +26,16 @@ namespace mi355 {
 // every state word is ONE naturally aligned 8-byte granule that carries its own tag, written by one agent-scope
 // relaxed atomic store (write-through, `sc1`) and polled with agent-scope relaxed atomic loads (`sc1`: served past
 // the CU's L1) -- there is no flag / payload ordering to get wrong.  The words are zeroed by a memset node in front
-// of every launch.  Forward progress: the grid is persistent and fully resident (one block per CU by LDS) and every
-// wave takes its chunks in ascending order, so the wave a look-back waits for is running or done; every spin is
-// bounded (kSelectSpinLimit polls) and a wave that gives up flags the result (count = ~0) instead of hanging the
-// device.
+// of every launch.  Forward progress WITHOUT assuming a resident grid: chunks are not dealt out by block index but CLAIMED
+// -- a wave takes its next chunks from a ticket counter (one agent-scope atomic add, two chunks ahead of use, zeroed by
+// the same memset node as the state words) -- so a chunk a look-back waits for always belongs to a wave that is running
+// and publishes its aggregate without waiting for anybody.  Blocks that the dispatcher holds back (another context's
+// kernel occupying CUs / LDS: contexts and streams are independent, include/mi355_scan.h) simply claim later chunks when
+// they start.  Round 2 assigned chunk = blockIdx.x * 4 + wave (+ stride): with part of the grid not resident, block 0's
+// second chunk waited for chunks of undispatched blocks until the spin limit and the call returned count = ~0.
+// The spin limit stays as a guard against a device that makes no progress at all; it is sound now: a wave that gives up
+// publishes status 3 (poison) for its chunk, every look-back that meets a poisoned word gives up too, and the count is
+// written with an atomic max (the entry point zeroes it), so ~0 always wins over a partial sum.
 //
 // Expansion, one 32-row word of every lane (2048 rows of the tile... in lane-major row order: lane l owns rows
 // [VPL l, VPL l + VPL) of a tile) at a time: writing ids lane by lane would make every store instruction touch 64
@@ -43,6 +49,12 @@ constexpr int select_tiles(int c) { return c > 16 ? 16 : (c >= 14 ? 4 : 8); }
 constexpr int kSelectWindow = 16;         // state words per lane and poll (1024 per wave)
 constexpr uint32_t kSelectSpinLimit = 1u << 20;
 constexpr unsigned long long kSelectValueMask = (1ull << 62) - 1ull;
+// the chunk-ticket counter sits behind the state words on its own 128-byte line (same allocation, same memset node)
+__host__ __device__ constexpr uint64_t select_ticket_index(uint64_t nchunks) { return (nchunks + 15) / 16 * 16 + 16; }
+__host__ __device__ constexpr uint64_t select_state_words(uint64_t nchunks) { return select_ticket_index(nchunks) + 16; }
+// a tile with at least 1 id per kSelectDenseRatio rows is expanded 64 consecutive rows at a time straight from the
+// registers (see expand): the cost of that form is per row, the cost of the LDS stage per id
+constexpr uint32_t kSelectDenseRatio = 8;
 
 template <int C, int MODE, int VPL>
 __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
@@ -67,8 +79,20 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
     uint16_t *st = stage[wave];
     const TileCtx<C, VPL> tc(a.n);
     const uint64_t nchunks = (tc.ntiles + K - 1) / K;
-    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
-    uint64_t chunk = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    unsigned long long *const ticket = a.tile_state + select_ticket_index(nchunks);
+    // claim `count` consecutive chunks: the first one's index in lane 0 (read with readfirstlane when it is needed)
+    auto claim = [&](unsigned long long count) -> unsigned long long {
+        unsigned long long t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(ticket, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return t;
+    };
+    auto uniform64 = [](unsigned long long v) -> uint64_t {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    uint64_t chunk = uniform64(claim(2)); // this wave's first two chunks
+    uint64_t chunk_next = chunk + 1;
 
     const uint32_t key[2] = {a.key[0], a.key[1]};
     const uint8_t *const mask = a.and_mask;
@@ -139,11 +163,15 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
                     const uint32_t status = (uint32_t)(s[k] >> 62);
                     const unsigned long long fmask = __ballot(status == 2);
                     const unsigned long long bmask = __ballot(status == 0);
+                    const unsigned long long pmask = __ballot(status == 3);
                     // the nearest chunk that knows its inclusive prefix ends the walk; every chunk nearer than it must
                     // at least have published its own count
                     const int stop = fmask ? __builtin_ctzll(fmask) : 64;
                     const unsigned long long need = stop >= 63 ? ~0ull : ((2ull << stop) - 1ull);
-                    if (bmask & need) {
+                    if (pmask & need) { // a chunk in front gave up: its prefix will never come
+                        gave_up = true;
+                        done = true;
+                    } else if (bmask & need) {
                         retry = true; // what was summed so far stays valid: resume at this group
                         pos -= 64 * k;
                     } else {
@@ -159,7 +187,7 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
             }
             before += (unsigned long long)wave_sum(acc) + prefix;
             if (retry) {
-                if (++spins > kSelectSpinLimit) {
+                if (++spins > kSelectSpinLimit || gave_up) {
                     gave_up = true;
                     break;
                 }
@@ -169,8 +197,9 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
             }
             if (!done) poll_issue(pos, s);
         }
-        if (lane == 0)
-            __hip_atomic_store(state + q, (2ull << 62) | ((before + q_hits) & kSelectValueMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) // (poison, not a partial prefix, when the walk was given up)
+            __hip_atomic_store(state + q, gave_up ? (3ull << 62) : ((2ull << 62) | ((before + q_hits) & kSelectValueMask)),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return before;
     };
 
@@ -270,6 +299,34 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
                 out += total;
                 continue;
             }
+            if (total >= (uint32_t)G::TILE_VALUES / kSelectDenseRatio) {
+                // Dense tile: no LDS stage.  The 64 rows [128 L + 64 h, +64) are two words of lane L: read them into an
+                // SGPR pair (v_readlane), make that pair the EXEC mask, and the hit lanes -- lane l = row l of the step --
+                // store their row id at the running offset + v_mbcnt.  One store instruction writes popcount(m)
+                // CONSECUTIVE ids (256 B at selectivity 1/2), ~12 mostly scalar instructions per 64 rows, no dependent
+                // LDS round trip anywhere: this is what one wave per SIMD can keep up, where the stage's ds_write -> wait
+                // -> ds_read -> store chains could not (5e8 ids of 1e9 rows: 1.49 ms, the unfused chain 1.11-1.23).
+                const bool roomy = out + total <= a.capacity; // wave-uniform
+                unsigned long long o = out;
+#pragma unroll 1
+                for (int L = 0; L < 64; L++) {
+#pragma unroll
+                    for (int h = 0; h < WORDS / 2; h++) {
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)b[2 * h], L);
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)b[2 * h + 1], L);
+                        const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+                        if (m) { // wave-uniform
+                            const uint32_t pos = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                            if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                                if (roomy || o + pos < a.capacity) a.rowids[o + pos] = row0 + (uint32_t)(L * VPL + 64 * h) + lane;
+                            }
+                            o += (unsigned long long)__builtin_popcountll(m);
+                        }
+                    }
+                }
+                out += total;
+                continue;
+            }
             const uint32_t first_half = __builtin_amdgcn_readlane(incl, 31); // ids of lanes 0..31
             // the stage holds the ids of half a tile: one pass when they fit, else lanes 0..31, then lanes 32..63
             const int npass = total <= (uint32_t)HALF ? 1 : 2;
@@ -343,7 +400,9 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
         if (want_ids) count_chunk(ntiles_q, pk, cw); // needs no prefix: in front of the poll's evaluation
         const unsigned long long before = look_back ? resolve(q, q_hits, s) : 0ull;
         if (want_ids && !gave_up) expand(q, ntiles_q, pk, before, cw);
-        if (q == nchunks - 1 && lane == 0) a.hits[0] = gave_up ? ~0ull : before + q_hits; // the column's hit count
+        // the column's hit count: atomic max over a word the entry point zeroed, so a give-up's ~0 (below) always wins
+        if (q == nchunks - 1 && lane == 0 && !gave_up)
+            __hip_atomic_fetch_max(a.hits, before + q_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     // Software pipeline over the wave's chunks: chunk g is resolved and expanded AFTER chunk g+1 has been decoded.  The
@@ -357,6 +416,8 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
     int pend_ntiles = 0;
     int buf = 0;
     while (chunk < nchunks) {
+        // the ticket of the chunk after next: back long before it is read at the bottom of this iteration
+        const unsigned long long pending_ticket = claim(1);
         const uint64_t tfirst = chunk * K;
         uint32_t(*const park)[64 * WORDS] = parked[wave][buf];
         uint32_t lane_hits = 0;
@@ -376,8 +437,8 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
                     for (int j = 0; j < WORDS; j++) mcur[j] = ((const uint32_t *)(mlds_wave + lane * (WORDS * 4)))[j];
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const uint64_t next = (k + 1 < K && tile + 1 < tc.ntiles) ? tile + 1 : (chunk + stride) * K;
-                if (next < tc.ntiles && (k + 1 < K || chunk + stride < nchunks)) issue_tile(next);
+                const uint64_t next = (k + 1 < K && tile + 1 < tc.ntiles) ? tile + 1 : chunk_next * K;
+                if (next < tc.ntiles && (k + 1 < K || chunk_next < nchunks)) issue_tile(next);
 
                 uint32_t r1[1][WORDS];
                 if constexpr (LK > 0) {
@@ -428,10 +489,11 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
         pend_hits = chunk_hits;
         pend_ntiles = ntiles_here;
         buf ^= 1;
-        chunk += stride;
+        chunk = chunk_next;
+        chunk_next = uniform64(pending_ticket);
     }
     if (pend) finish(pend_chunk, pend_hits, pend_ntiles, parked[wave][buf ^ 1]);
-    if (gave_up && lane == 0) a.hits[0] = ~0ull;
+    if (gave_up && lane == 0) __hip_atomic_fetch_max(a.hits, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 } // namespace mi355

@@ -307,7 +307,8 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
     }
     case kOpSelect: {
         // predicate -> row ids: one block per CU (LDS: tiles + mask image + 16 KiB id stage per wave), every wave on a
-        // chunk of select_tiles(C) tiles; the grid must be fully resident (the look-back waits for running waves)
+        // chunk of select_tiles(C) tiles.  Chunks are claimed from a ticket counter, so the grid need not be resident
+        // as a whole (another context's kernel may hold CUs): a look-back only ever waits for running waves
         constexpr int VPL = scan_vpl(C, kModeRange);
         using G = ScanGeom<C, VPL>;
         const uint64_t ntiles = (r.scan.n + G::TILE_VALUES - 1) / G::TILE_VALUES;

@@ -49,6 +49,10 @@ def bitmap_bytes(rows: int) -> int:
 # the exchange step
 # ---------------------------------------------------------------------------------------------------------------
 
+class ExchangeUnavailable(RuntimeError):
+    """the RCCL exchange of the C ABI could not be set up -- raised on EVERY rank of the group together"""
+
+
 class TorchExchange:
     """Exchange over a torch.distributed process group: gloo on CPU tensors (tests, rehearsals on a box with fewer
     GPUs than ranks -- device tensors are staged through host memory), or torch's own NCCL group.
@@ -109,30 +113,64 @@ class TorchExchange:
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
         return total.to(dev)
 
+    def info(self) -> Tuple[int, int]:
+        return self.world, self.rank
+
+
+def _flag_all_ok(ok: bool, group=None) -> bool:
+    """True iff `ok` on EVERY rank of the torch.distributed group (MIN all-reduce on the group's own device type)"""
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
 
 class RcclExchange:
     """The product path: the exchange entry points of the C ABI (direct RCCL over xGMI).  One communicator rank per
-    process; the unique id travels over the torch.distributed group that launched the ranks."""
+    process; the unique id travels over the torch.distributed group that launched the ranks.
+
+    Construction is COLLECTIVE and every rank leaves it with the same verdict (ExchangeUnavailable on all or on none):
+    a one-sided failure would otherwise leave peers blocked in a broadcast / in ncclCommInitRank, or mix transports.
+      1. every rank checks that librccl loads and answers (mi355_comm_get_unique_id); the flags are MIN-reduced;
+      2. rank 0 ALWAYS broadcasts -- its id (made in step 1), never an early exit in front of the broadcast;
+      3. every rank creates its communicator rank; the outcomes are MIN-reduced again, and a communicator that exists on
+         some ranks only is destroyed before ExchangeUnavailable is raised everywhere."""
 
     name = "mi355 C ABI (RCCL)"
 
     def __init__(self, engine, group=None):
         from . import _capi
-        from ._capi import check, lib
+        from ._capi import lib
 
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        ident = [None]
-        if self.rank == 0:
-            buf = (C.c_uint8 * _capi.COMM_ID_BYTES)()
-            check(lib().mi355_comm_get_unique_id(buf))
-            ident[0] = bytes(buf)
+        self._comm = None
+        buf = (C.c_uint8 * _capi.COMM_ID_BYTES)()
+        rc = lib().mi355_comm_get_unique_id(buf)
+        why = None if rc == 0 else f"rank {self.rank}: {lib().mi355_last_error().decode()}"
+        if not _flag_all_ok(rc == 0, group):
+            raise ExchangeUnavailable(why or "librccl unavailable on another rank")
+        ident = [bytes(buf) if self.rank == 0 else None]
         src = 0 if group is None else dist.get_global_rank(group, 0)
         dist.broadcast_object_list(ident, src=src, group=group)
-        self._comm = C.c_void_p()
+        comm = C.c_void_p()
         idbuf = (C.c_uint8 * _capi.COMM_ID_BYTES).from_buffer_copy(ident[0])
-        check(lib().mi355_comm_create(engine._ctx, self.world, self.rank, idbuf, C.byref(self._comm)))
+        rc = lib().mi355_comm_create(engine._ctx, self.world, self.rank, idbuf, C.byref(comm))
+        why = None if rc == 0 else f"rank {self.rank}: {lib().mi355_last_error().decode()}"
+        if rc == 0:
+            self._comm = comm
+        if not _flag_all_ok(rc == 0, group):
+            self.close()
+            raise ExchangeUnavailable(why or "mi355_comm_create failed on another rank")
+
+    def info(self) -> Tuple[int, int]:
+        """(world, rank) as the communicator itself reports them (mi355_comm_info)"""
+        from ._capi import check, lib
+
+        w, r = C.c_int(), C.c_int()
+        check(lib().mi355_comm_info(self._comm, C.byref(w), C.byref(r)))
+        return w.value, r.value
 
     def close(self) -> None:
         from ._capi import lib
@@ -179,7 +217,7 @@ class RcclExchange:
 def make_exchange(engine=None, group=None):
     """RCCL through the C ABI when the ranks own distinct GPUs (process group backend "nccl"); the torch.distributed
     transport for gloo groups (CPU tests; several ranks sharing one GPU, which RCCL refuses).  MI355_EXCHANGE=torch|rccl
-    overrides."""
+    overrides.  Collective: every rank returns the same kind of exchange, or every rank raises ExchangeUnavailable."""
     want = os.environ.get("MI355_EXCHANGE", "")
     backend = dist.get_backend(group)
     if want == "rccl" or (want != "torch" and backend == "nccl" and engine is not None and hasattr(engine, "_ctx")):
@@ -242,10 +280,23 @@ class ShardedColumn:
         the per-rank counts travel as ONE all-reduce of a one-hot vector; every rank's ids are then received at their
         final offset of the root's id list (shards are row ranges in rank order, so the concatenation is ascending)."""
         eng, ex, dev = self.engine, self.exchange, self._device()
-        ids, cnt = eng.scan_select(op, a, self.col, capacity=max(self.rows, 1), b=b, first_row=self.base_row + self.first)
-        onehot = torch.zeros(self.world, dtype=torch.int64, device=dev)
-        onehot[self.rank] = cnt.to(dev).reshape(())
-        counts = [int(x) for x in ex.sum_hits(onehot, engine=eng).cpu().tolist()]  # (the host needs them to size the receives)
+        # ids cost 8 B each: start with room for 1 row in 16 (never the 8 B x rows of the worst case up front) and run the
+        # shard again with the exact count when the predicate turns out denser (the count is the total whatever the capacity)
+        cap = max(1, min(self.rows, max(1 << 16, self.rows // 16)))
+        ids, cnt = eng.scan_select(op, a, self.col, capacity=cap, b=b, first_row=self.base_row + self.first)
+        mine = int(cnt.reshape(-1)[0].item())
+        if mine > cap:
+            ids, cnt = eng.scan_select(op, a, self.col, capacity=mine, b=b, first_row=self.base_row + self.first)
+            mine = int(cnt.reshape(-1)[0].item())
+        # a count of UINT64_MAX (-1 as int64) is the engine's "selection failed" flag: it must not become a buffer size.
+        # Decided collectively -- one more slot of the same all-reduce -- so that every rank raises, none is left in a send
+        onehot = torch.zeros(self.world + 1, dtype=torch.int64, device=dev)
+        onehot[self.rank] = max(mine, 0)
+        onehot[self.world] = 1 if mine < 0 else 0
+        summed = [int(x) for x in ex.sum_hits(onehot, engine=eng).cpu().tolist()]  # (the host needs them to size the receives)
+        if summed[self.world]:
+            raise RuntimeError(f"scan_select failed on {summed[self.world]} rank(s) (count = UINT64_MAX)")
+        counts = summed[: self.world]
         sizes = [8 * k for k in counts]
         offsets = [sum(sizes[:r]) for r in range(self.world)]
         out = torch.empty(sum(counts), dtype=torch.int64, device=dev) if self.rank == dst else None

@@ -143,3 +143,32 @@ def test_reference_own_benchmark_harness_runs_on_the_engine(args):
     assert "mismatch" not in res.stdout, res.stdout[-4000:]
     rows = parse_output(res.stdout)
     assert len(rows) >= 4, res.stdout
+
+
+@pytest.mark.gpu
+def test_cli_runs_the_reference_predicate_sweep():
+    """the reference's own sweep -- `<binary> 40 1 sharedscan P` for P = 1 .. 512
+    (scripts/prepare_shared_scan_results.py:22-31), parsed with its rule -- through cli/shared_simd_scan_mi355, every run's
+    self-checks silent.  tools/cli_sweep.py is that script restated; the full sweep's CSV is profiles/r03_cli_sweep_P1_512.csv
+    (MI355_FULL_SWEEP=1 runs all 512 here; by default every 9th count plus both ends and the kernel boundaries)."""
+    import io
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import cli_sweep
+    finally:
+        sys.path.pop(0)
+    if not os.path.exists(CLI):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "shared_simd_scan_amd", "csrc"), "cli"], check=True)
+    if os.environ.get("MI355_FULL_SWEEP") == "1":
+        counts = list(range(1, 513))
+    else:
+        counts = sorted(set(range(1, 513, 9)) | {1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 33, 40, 47, 63, 64, 65, 127, 128, 129, 255, 256,
+                                                 257, 300, 500, 511, 512})
+    buf = io.StringIO()
+    bad = cli_sweep.sweep(CLI, 40, 1, counts, buf)
+    assert not bad, bad[:5]
+    rows = buf.getvalue().strip().splitlines()
+    assert rows[0] == "data_size,predicate_count,variant,avg_runtime_ms"
+    assert len(rows) == 1 + 2 * len(counts)  # per count: per-predicate and linear

@@ -1004,7 +1004,10 @@ def test_scan_select_matches_numpy(O, eng, c, n):
     v = vals.astype(np.int64)
     vmax = (1 << c) - 1
     a = int(vals[n // 2])
+    # (selectivities 1/2 and ~1: tiles expanded 64 rows at a time from the registers; ~1/8 .. 1/64: through the LDS
+    # stage; a single key: mostly sparse tiles written straight from the lanes)
     for op, x, y, expect in (("==", a, 0, v == a), ("<=", vmax // 2, 0, v <= vmax // 2), ("!=", a, 0, v != a),
+                             ("<", vmax // 8 + 2, 0, v < vmax // 8 + 2), ("<=", vmax // 64, 0, v <= vmax // 64),
                              ("between", 5, 2, np.zeros(n, bool))):
         ids, cnt = eng.scan_select(op, x, col, capacity=n, b=y, first_row=10_000_000_000)
         want = np.nonzero(expect)[0].astype(np.int64) + 10_000_000_000
@@ -1027,6 +1030,51 @@ def test_scan_select_matches_numpy(O, eng, c, n):
     assert int(cnt.item()) == expect.shape[0]
     assert np.array_equal(ids[: min(cap, expect.shape[0])].cpu().numpy(), expect[:cap])
     torch.cuda.synchronize()
+
+
+def test_scan_select_beside_another_contexts_long_kernels(O):
+    """Contexts are independent (include/mi355_scan.h): a fused selection on context A / stream A while context B /
+    stream B keeps the device busy with back-to-back 1e9-row shared scans.  The selection's blocks then start at
+    different times (some only when B's blocks retire); chunks are claimed from a ticket counter, so the look-back never
+    waits for a block that has not started: count and ids exact, never the give-up flag UINT64_MAX (round 2 dealt
+    chunks out by block index and could return it here)."""
+    import torch
+
+    from shared_simd_scan_amd import ScanEngine
+
+    n, c = 1_000_000_000, 9
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    A, B = ScanEngine(0, stream=sA), ScanEngine(0, stream=sB)
+    col = A.generate("splitmix", n, c, 42)
+    key = int(O.gen_values("splitmix", 1, c, 42, first=12345)[0])
+    refs = []
+    for op, x in (("==", key), ("<", 256)):
+        bm, hits = A.scan_where(op, x, col)
+        h = int(hits.item())
+        ids_ref, _ = A.bitmap_to_rowids(bm, n, capacity=h)
+        refs.append((op, x, h, ids_ref))
+        del bm
+    torch.cuda.synchronize()
+    P = 64
+    keys = [(37 * k + 3) % 512 for k in range(P)]
+    stride = ((n + 7) // 8 + 255) // 256 * 256
+    out = torch.empty((P, stride), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for op, x, h, ids_ref in refs:
+            for _ in range(3):  # ~3 ms each on stream B: the selection below is enqueued while these run
+                B.shared_scan(keys, col, out=out, hits=False)
+            ids, cnt = A.scan_select(op, x, col, capacity=h)
+            for _ in range(2):
+                B.shared_scan(keys, col, out=out, hits=False)
+            sA.synchronize()
+            k = int(cnt.item())
+            assert k == h, (op, rep, k, h)
+            assert torch.equal(ids[:h], ids_ref[:h]), (op, rep)
+            del ids
+    torch.cuda.synchronize()
+    del out, col, refs
+    torch.cuda.empty_cache()
 
 
 def test_scan_select_1e9_chain(O, eng):

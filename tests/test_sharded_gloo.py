@@ -273,3 +273,64 @@ def test_c_abi_exchange_single_rank():
     assert L.mi355_allreduce_hits_dev(eng._ctx, comm, hits.data_ptr(), 1) == 0
     assert int(hits.item()) == ref_hits
     assert L.mi355_comm_destroy(comm) == 0
+
+
+def test_missing_librccl_is_an_error_not_a_crash():
+    """a host without librccl: mi355_comm_get_unique_id / mi355_comm_create return MI355_E_COMM with dlopen's message
+    (round 2 called dlerror() twice and handed std::string a null pointer).  MI355_RCCL_LIB forces the miss; a fresh
+    process, because the library is looked up once per process."""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes as C, sys\n"
+        "from shared_simd_scan_amd import lib\n"
+        "L = lib(); buf = (C.c_uint8 * 128)()\n"
+        "rc = L.mi355_comm_get_unique_id(buf); msg = L.mi355_last_error().decode()\n"
+        "print(rc, msg)\n"
+        "sys.exit(0 if (rc != 0 and 'librccl not found' in msg and 'no-such-librccl' in msg) else 1)\n")
+    env = dict(os.environ, MI355_RCCL_LIB="/nonexistent/no-such-librccl.so")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+
+
+def _bench_2ranks(extra_env, extra_args=()):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_BACKEND="gloo", **extra_env)
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "40000000", "--steps", "5",
+                          "--warmup", "2", *extra_args], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_prints_strong_headline_and_weak_beside_it():
+    """`python bench.py --gpus 2` (gloo rehearsal: two ranks share the one GPU): `value` is ONE column split over the
+    ranks, the weak figure sits beside it, per-rank kernel times and the exchange's own rank count are there"""
+    res, line = _bench_2ranks({})
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    assert line["config"]["rows_total"] == 40_000_000 and sum(line["config"]["rows_per_gpu"]) == 40_000_000
+    assert all(r % 8192 == 0 for r in line["config"]["rows_per_gpu"][:-1])
+    assert line["value"] == line["strong_values_per_s"] > 0 and line["weak_values_per_s"] > 0
+    assert len(line["per_rank_kernel_ms"]) == 2 and all(x > 0 for x in line["per_rank_kernel_ms"])
+    assert line["ranks_seen"] == 2 and line["comm_world"] == 2
+    assert line["gather_ms"] > 0 and "gather_error" not in line
+    assert line["hits"] == line["config"]["rows_per_gpu"][0] // 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,status", [("raise", 4), ("hang", 3), ("hang1", 3)])
+def test_bench_failed_exchange_prints_the_line_and_exits_non_zero(mode, status):
+    """a failed (raise) or stuck (hang on every rank / on rank 1 only) exchange step: the scan line is still printed and
+    the run's exit status is NOT zero"""
+    res, line = _bench_2ranks({"BENCH_FORCE_EXCHANGE_FAILURE": mode}, ("--gather-timeout", "15"))
+    assert res.returncode != 0, res.stdout[-2000:]
+    assert line is not None and line["value"] > 0 and line["gather_error"], res.stdout[-2000:] + res.stderr[-2000:]
+    assert f"exit status {status}" in line["gather_error"] or status == 4

@@ -10,11 +10,57 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def select_rows(args, eng, col, n, c, nb, pk, timed, report):
+    """predicate -> row ids, fused (one launch) against the chain scan -> bitmap -> row ids (4 launches), per selectivity"""
+    import torch
+
+    key = 77
+    out = torch.empty(nb + 64, dtype=torch.uint8, device="cuda")
+    h1 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    sels = (("1/512", "==", key), ("1/64", "<", max(1, (1 << c) // 64)), ("1/8", "<", max(1, (1 << c) // 8)), ("1/2", "<", (1 << c) // 2))
+    if args.only_select:
+        sels = tuple(x for x in sels if x[0] in args.only_select.split(","))
+    for name, op, x in sels:
+        bm, hh = eng.scan_where(op, x, col)
+        cnt = int(hh.item())
+        ids = None
+
+        def chain():
+            nonlocal ids
+            b2, _ = eng.scan_where(op, x, col, bitmap=out, hits=h1)
+            ids = eng.bitmap_to_rowids(b2, n, capacity=cnt)
+
+        def rowids_only():
+            nonlocal ids
+            ids = eng.bitmap_to_rowids(bm, n, capacity=cnt)
+
+        def fused():
+            nonlocal ids
+            ids = eng.scan_select(op, x, col, capacity=cnt)
+
+        report(f"bitmap_to_rowids selectivity {name}", timed(rowids_only, 5), nb + 8 * cnt, f"{cnt} ids")
+        t_chain = timed(chain, 5)
+        report(f"scan -> bitmap -> row ids, selectivity {name}", t_chain, pk + nb + 2 * nb + 8 * cnt, "4 launches; bitmap written once, read twice")
+        t_fused = timed(fused, 5)
+        report(f"scan_select (fused), selectivity {name}", t_fused, pk + 8 * cnt,
+               f"1 launch, no bitmap in HBM: {3 * nb / 1e6:.0f} MB less traffic, {t_chain / t_fused:.2f}x the chain's speed")
+        if name == "1/512":
+            col_b = eng.generate("splitmix", n, 12, 4242)
+            cnt_dev = torch.tensor([cnt], dtype=torch.int64, device="cuda")
+            taken = torch.empty(cnt, dtype=torch.int32, device="cuda")
+            report(f"gather: another column's values at those {cnt} ids", timed(lambda: eng.gather(col_b, ids[0][:cnt], cnt_dev, out=taken), 10),
+                   12 * cnt, "(\"take\": two dwords per id; algorithmic = 8 B id + 4 B value per row)")
+            del col_b, taken
+        del ids
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--bits", type=int, default=9)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--select-only", dest="only_select", default="", help="only the selection rows, e.g. 1/2,1/8,1/64,1/512")
     args = ap.parse_args()
     import torch
 
@@ -41,6 +87,8 @@ def main():
         print(f"{name:44s} {ms:8.4f} ms  {nbytes / ms / 1e6:7.0f} GB/s algorithmic  {n / ms * 1e3:.3e} rows/s  {note}", flush=True)
 
     col = eng.generate("splitmix", n, c, 42)
+    if args.only_select:
+        return select_rows(args, eng, col, n, c, nb, pk, timed, report)
     report("generate splitmix (write packed)", timed(lambda: eng.generate("splitmix", n, c, 42), 5), pk)
     vals = eng.decompress(col)  # int32[n]: input of the device packer
     report("compress u32 -> packed", timed(lambda: eng.compress(vals, c), 5), 4 * n + pk)
@@ -88,39 +136,7 @@ def main():
     report("col1 < a AND col2 >= b: scan2, count only", timed(lambda: eng.scan2(col, "<", (1 << c) // 4, col2, ">=", (1 << c) // 8, hits=h1, count_only=True)), 2 * pk)
     del col2
     torch.cuda.empty_cache()
-    for name, op, x in (("1/512", "==", key), ("1/2", "<", (1 << c) // 2)):
-        bm, hh = eng.scan_where(op, x, col)
-        cnt = int(hh.item())
-        ids = None
-
-        def chain():
-            nonlocal ids
-            b2, _ = eng.scan_where(op, x, col, bitmap=out, hits=h1)
-            ids = eng.bitmap_to_rowids(b2, n, capacity=cnt)
-
-        def rowids_only():
-            nonlocal ids
-            ids = eng.bitmap_to_rowids(bm, n, capacity=cnt)
-
-        def fused():
-            nonlocal ids
-            ids = eng.scan_select(op, x, col, capacity=cnt)
-
-        report(f"bitmap_to_rowids selectivity {name}", timed(rowids_only, 5), nb + 8 * cnt, f"{cnt} ids")
-        t_chain = timed(chain, 5)
-        report(f"scan -> bitmap -> row ids, selectivity {name}", t_chain, pk + nb + 2 * nb + 8 * cnt, "4 launches; bitmap written once, read twice")
-        t_fused = timed(fused, 5)
-        report(f"scan_select (fused), selectivity {name}", t_fused, pk + 8 * cnt,
-               f"1 launch, no bitmap in HBM: {3 * nb / 1e6:.0f} MB less traffic, {t_chain / t_fused:.2f}x the chain's speed")
-        if name == "1/512":
-            col_b = eng.generate("splitmix", n, 12, 4242)
-            cnt_dev = torch.tensor([cnt], dtype=torch.int64, device="cuda")
-            taken = torch.empty(cnt, dtype=torch.int32, device="cuda")
-            report(f"gather: another column's values at those {cnt} ids", timed(lambda: eng.gather(col_b, ids[0][:cnt], cnt_dev, out=taken), 10),
-                   12 * cnt, "(\"take\": two dwords per id; algorithmic = 8 B id + 4 B value per row)")
-            del col_b, taken
-        del ids
-        torch.cuda.empty_cache()
+    select_rows(args, eng, col, n, c, nb, pk, timed, report)
 
 
 if __name__ == "__main__":
