@@ -26,13 +26,17 @@ namespace mi355 {
 // every state word is ONE naturally aligned 8-byte granule that carries its own tag, written by one agent-scope
 // relaxed atomic store (write-through, `sc1`) and polled with agent-scope relaxed atomic loads (`sc1`: served past
 // the CU's L1) -- there is no flag / payload ordering to get wrong.  The words are zeroed by a memset node in front
-// of every launch.  Forward progress WITHOUT assuming a resident grid: chunks are not dealt out by block index but CLAIMED
-// -- a wave takes its next chunks from a ticket counter (one agent-scope atomic add, two chunks ahead of use, zeroed by
-// the same memset node as the state words) -- so a chunk a look-back waits for always belongs to a wave that is running
-// and publishes its aggregate without waiting for anybody.  Blocks that the dispatcher holds back (another context's
-// kernel occupying CUs / LDS: contexts and streams are independent, include/mi355_scan.h) simply claim later chunks when
-// they start.  Round 2 assigned chunk = blockIdx.x * 4 + wave (+ stride): with part of the grid not resident, block 0's
-// second chunk waited for chunks of undispatched blocks until the spin limit and the call returned count = ~0.
+// of every launch.  Forward progress WITHOUT assuming a resident grid: chunks are not dealt out by block index but CLAIMED,
+// a BLOCK at a time -- wave 0 takes the block's next four chunks from a ticket counter (one agent-scope atomic add per
+// generation, two generations ahead of use; zeroed by the same memset node as the state words) and hands them to the
+// block's waves through LDS behind a barrier -- so a chunk a look-back waits for always belongs to a block that is
+// running, whose waves publish their aggregates without waiting for anybody.  Blocks that the dispatcher holds back
+// (another context's kernel occupying CUs / LDS: contexts and streams are independent, include/mi355_scan.h) simply
+// claim later chunks when they start.  Round 2 assigned chunk = blockIdx.x * 4 + wave (+ stride): with part of the grid
+// not resident, block 0's second chunk waited for chunks of undispatched blocks until the spin limit and the call
+// returned count = ~0.  (One ticket per WAVE and chunk was tried first: 7630 same-address device-scope atomics of ~40 ns
+// each in a 0.27 ms kernel -- the counter became the bottleneck, 0.36 ms.  Per block it is a quarter of that, off the
+// critical path: the atomic's return is not waited for until a tile later, see the tile loop.)
 // The spin limit stays as a guard against a device that makes no progress at all; it is sound now: a wave that gives up
 // publishes status 3 (poison) for its chunk, every look-back that meets a poisoned word gives up too, and the count is
 // written with an atomic max (the entry point zeroes it), so ~0 always wins over a partial sum.
@@ -80,19 +84,7 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
     const TileCtx<C, VPL> tc(a.n);
     const uint64_t nchunks = (tc.ntiles + K - 1) / K;
     unsigned long long *const ticket = a.tile_state + select_ticket_index(nchunks);
-    // claim `count` consecutive chunks: the first one's index in lane 0 (read with readfirstlane when it is needed)
-    auto claim = [&](unsigned long long count) -> unsigned long long {
-        unsigned long long t = 0;
-        if (lane == 0) t = __hip_atomic_fetch_add(ticket, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return t;
-    };
-    auto uniform64 = [](unsigned long long v) -> uint64_t {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-        return ((uint64_t)hi << 32) | lo;
-    };
-    uint64_t chunk = uniform64(claim(2)); // this wave's first two chunks
-    uint64_t chunk_next = chunk + 1;
+    __shared__ unsigned long long mail[2]; // first chunk of the block's generation g + 2, posted by wave 0 at the bottom of generation g
 
     const uint32_t key[2] = {a.key[0], a.key[1]};
     const uint8_t *const mask = a.and_mask;
@@ -112,7 +104,32 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
         tc.template issue<AUX>(a.packed, t, lds_wave, lane);
     };
 
-    if (chunk < nchunks) issue_tile(chunk * K);
+    // (A/B switches, timing only -- the results are the same: flags bit 3 = chunks dealt out by block index as in round 2,
+    // which is only safe while the whole grid is resident; bit 4 = no barrier per generation, with bit 3 only)
+    const bool by_index = (a.flags & 8u) != 0, no_barrier = (a.flags & 24u) == 24u;
+    const unsigned long long gen_stride = (unsigned long long)gridDim.x * kWavesPerBlock;
+    // the block's first two generations: one claim of 4 chunks each (two dependent atomics: the second lands behind the
+    // first claims of the blocks that started at about the same time, so generation 1 lies mostly above generation 0)
+    if (threadIdx.x == 0) {
+        if (by_index) {
+            mail[0] = (unsigned long long)blockIdx.x * kWavesPerBlock;
+            mail[1] = mail[0] + gen_stride;
+        } else {
+            const unsigned long long t0 = __hip_atomic_fetch_add(ticket, (unsigned long long)kWavesPerBlock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mail[0] = t0; // (the LDS write needs the value: the first atomic has returned before the second is issued)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            mail[1] = __hip_atomic_fetch_add(ticket, (unsigned long long)kWavesPerBlock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    auto uniform64 = [](unsigned long long v) -> uint64_t { // (the value is the same in every lane: keep it in SGPRs)
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    uint64_t base = uniform64(mail[0]), base_next = uniform64(mail[1]); // first chunk of this / the next generation of the block
+    __syncthreads(); // (both read before wave 0 posts generation 2 into mail[0])
+    if (base + wave < nchunks) issue_tile((base + wave) * K);
     if constexpr (LK > 0) {
         constexpr uint32_t fmask = (1u << C) - 1u;
         for (uint32_t e = threadIdx.x; e < (1u << (LK * C)); e += kBlockThreads) {
@@ -415,9 +432,17 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
     unsigned long long pend_hits = 0;
     int pend_ntiles = 0;
     int buf = 0;
-    while (chunk < nchunks) {
-        // the ticket of the chunk after next: back long before it is read at the bottom of this iteration
-        const unsigned long long pending_ticket = claim(1);
+    uint32_t gen = 0;
+    while (base < nchunks) { // block-uniform: the four waves leave together (a wave whose chunk lies behind the column idles a round)
+        const uint64_t chunk = base + wave, chunk_next = base_next + wave;
+        // wave 0: the block's ticket for generation gen + 2.  Issued behind the DMA of this chunk's first tile, so the
+        // first tile waits with vmcnt(1) -- everything but this youngest operation -- and the atomic's round trip passes
+        // behind that tile's decode; its value is read at the bottom of the iteration
+        unsigned long long pending_ticket = 0;
+        const bool claiming = wave == 0 && !by_index;
+        if (claiming && lane == 0)
+            pending_ticket = __hip_atomic_fetch_add(ticket, (unsigned long long)kWavesPerBlock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool have = chunk < nchunks;
         const uint64_t tfirst = chunk * K;
         uint32_t(*const park)[64 * WORDS] = parked[wave][buf];
         uint32_t lane_hits = 0;
@@ -425,9 +450,12 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
 #pragma unroll 1
         for (int k = 0; k < K; k++) {
             const uint64_t tile = tfirst + k;
-            if (tile < tc.ntiles) { // wave-uniform
+            if (have && tile < tc.ntiles) { // wave-uniform
                 ntiles_here = k + 1;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (claiming && k == 0)
+                    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 uint32_t w[G::LANE_DWORDS];
                 read_lane_data<C, VPL>(lds_wave, lane, w);
                 uint32_t mcur[WORDS];
@@ -479,18 +507,32 @@ __global__ __launch_bounds__(kBlockThreads, 1) void select_kernel(ScanArgs a)
                 }
             }
         }
-        // the chunk's hits, published as its aggregate (chunk 0: as the first inclusive prefix)
-        const unsigned long long chunk_hits = wave_sum(lane_hits);
-        if (lane == 0)
-            __hip_atomic_store(state + chunk, ((chunk == 0 ? 2ull : 1ull) << 62) | chunk_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long chunk_hits = 0;
+        if (have) {
+            // the chunk's hits, published as its aggregate (chunk 0: as the first inclusive prefix)
+            chunk_hits = wave_sum(lane_hits);
+            if (lane == 0)
+                __hip_atomic_store(state + chunk, ((chunk == 0 ? 2ull : 1ull) << 62) | chunk_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (pend) finish(pend_chunk, pend_hits, pend_ntiles, parked[wave][buf ^ 1]);
-        pend = true;
+        pend = have;
         pend_chunk = chunk;
         pend_hits = chunk_hits;
         pend_ntiles = ntiles_here;
         buf ^= 1;
-        chunk = chunk_next;
-        chunk_next = uniform64(pending_ticket);
+        // hand-over of generation gen + 2: posted before the barrier, read behind it; the slot is written again two
+        // barriers later, when every wave has long read it
+        if (by_index) {
+            if (!no_barrier) __syncthreads();
+            base = base_next;
+            base_next += gen_stride;
+        } else {
+            if (wave == 0 && lane == 0) mail[gen & 1] = pending_ticket;
+            __syncthreads();
+            base = base_next;
+            base_next = uniform64(mail[gen & 1]);
+        }
+        gen++;
     }
     if (pend) finish(pend_chunk, pend_hits, pend_ntiles, parked[wave][buf ^ 1]);
     if (gave_up && lane == 0) __hip_atomic_fetch_max(a.hits, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

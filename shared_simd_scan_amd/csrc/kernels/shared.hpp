@@ -761,10 +761,13 @@ __global__ __launch_bounds__(kBlockThreads) void shared_lut_kernel(ScanArgs a)
 //   C <= 10: one table of 2^C dwords per 32 keys; C > 10: ceil(C/8) byte-digit tables of 256 dwords, ANDed.
 // LAYOUT 0: per-predicate bitmaps, pass-major (a wave-store is 512 B contiguous per key).
 // LAYOUT 1: linear; every 8-value group's row of P bytes is written start to end, 32 bytes per lookup round.
-template <int C> struct WideLutGeom {
-    static constexpr int ND = C <= 10 ? 1 : (C + 7) / 8;
+// BIG: fewer, wider digits where byte digits need three or four -- c = 17 .. 20: two digits of 9 / 10 bits (4 / 8 KiB per 32
+// keys instead of 3 KiB), c = 25 .. 30: three of 9 / 10 bits (6 / 12 KiB instead of 4 KiB): one lookup, one AND and a digit
+// extraction less per value and round, for key counts whose tables still fit (the launcher decides).
+template <int C, bool BIG = false> struct WideLutGeom {
+    static constexpr int ND = C <= 10 ? 1 : (BIG && C >= 17 && C <= 20) ? 2 : (BIG && C >= 25 && C <= 30) ? 3 : (C + 7) / 8;
     static constexpr bool SINGLE = ND == 1;
-    static constexpr int DIGIT_BITS = SINGLE ? C : 8;
+    static constexpr int DIGIT_BITS = SINGLE ? C : (BIG ? (C + ND - 1) / ND : 8);
     static constexpr int ENTRIES = 1 << DIGIT_BITS;
     static constexpr int TABLE_DWORDS = ND * ENTRIES; // per pass of 32 keys
     static constexpr int TABLE_BYTES = TABLE_DWORDS * 4;
@@ -992,11 +995,18 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide_kernel(ScanArgs a)
 // 8 keys): afterwards R[b][q] IS the bitmap word of key 8b + q -- 0.34 operations per result, no gather.
 // REGCNT: hit counts of a single 32-key round (P <= 32) in 32 registers of the lane (see below); its own instantiation
 // because the registers would cost the other paths a resident wave (c = 11, 12: 248 -> 256 + spills to AGPRs).
-template <int C, int AUX_, int VPL, bool REGCNT = false>
+// RC (hit counts in registers): 0 none; 1 one round of 32 keys, a 32-bit register per key (P <= 32); 2 two rounds, two
+// keys per register in 16-bit halves, flushed every kPackedFlushTiles tiles (P <= 64) -- for the widths of digit tables, where
+// the per-tile wave reductions + LDS atomics of block_hits_add8 cost the 32-key rounds a quarter of their time at two waves
+// per SIMD (2.5e8 x 17 bit, P = 64: 0.837 ms with hit counts against 0.657 without).
+constexpr uint32_t kPackedFlushTiles = 512; // a lane adds at most 64 per key and tile: 512 x 64 < 2^16
+
+template <int C, int AUX_, int VPL, int RC = 0, bool BIG = false>
 __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
 {
     using G = ScanGeom<C, VPL>;
-    using L = WideLutGeom<C>;
+    using L = WideLutGeom<C, BIG>;
+    constexpr bool REGCNT = RC == 1;
     constexpr int WORDS = G::WORDS;
     constexpr int AUX = AUX_ & 15;
     constexpr int NTS = (AUX_ & 32) ? 2 : ((AUX_ & 16) ? 1 : 0); // result stores: 1 non-temporal, 2 write-through (sc1)
@@ -1024,12 +1034,40 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
     const uint32_t P = a.nkeys;
     const uint32_t npass32 = (P + 31) / 32;
     constexpr bool reg_counts = REGCNT; // (the launcher picks it for P <= 32 with hit counts)
-    const bool use_hist = HIST && P >= 64;
+    const bool use_hist = HIST && P >= 64 && RC == 0;
     uint32_t acc[REGCNT ? 4 : 1][8];
 #pragma unroll
     for (int b = 0; b < (REGCNT ? 4 : 1); b++)
 #pragma unroll
         for (int q = 0; q < 8; q++) acc[b][q] = 0;
+    // RC == 2: acc2[round][key-byte][pair]: keys 32 p + 8 b + 2 q (low half) and + 1 (high half)
+    uint32_t acc2[RC == 2 ? 2 : 1][4][4];
+#pragma unroll
+    for (int p = 0; p < (RC == 2 ? 2 : 1); p++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc2[p][b][q] = 0;
+    uint32_t tiles_counted = 0;
+    auto flush_packed = [&]() {
+        if constexpr (RC == 2) {
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t lo = wave_sum(acc2[p][b][q] & 0xffffu), hi = wave_sum(acc2[p][b][q] >> 16);
+                        acc2[p][b][q] = 0;
+                        if (lane == 0) {
+                            unsigned long long *slot = a.scratch + (blockIdx.x % kHitSlots) * kMaxKeys + 32 * p + 8 * b + 2 * q;
+                            if (lo) __hip_atomic_fetch_add(slot, (unsigned long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (hi) __hip_atomic_fetch_add(slot + 1, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+        }
+        tiles_counted = 0;
+    };
 
     if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
 
@@ -1073,8 +1111,8 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
 
         // (flags bit 2, experiment: every wave starts its round-robin over the 32-key rounds at a different round, so the
         // waves of the lock-stepped grid do not all write the same 32 output streams at the same time)
-        const uint32_t rot = (a.flags & 4u) ? (uint32_t)((blockIdx.x * kWavesPerBlock + wave) % npass32) : 0u;
-        for (uint32_t pi = 0; pi < npass32; pi++) {
+        const uint32_t rot = (RC != 2 && (a.flags & 4u)) ? (uint32_t)((blockIdx.x * kWavesPerBlock + wave) % npass32) : 0u;
+        auto do_round = [&](const uint32_t pi) __attribute__((always_inline)) {
             const uint32_t p32 = pi + rot < npass32 ? pi + rot : pi + rot - npass32;
             const uint32_t *table = lut + p32 * L::TABLE_DWORDS;
             const uint32_t nb = ((P - p32 * 32) < 32 ? (P - p32 * 32) + 7 : 39) / 8; // key-bytes in use, 1..4
@@ -1112,6 +1150,17 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
                         for (int q = 0; q < 8; q++)
 #pragma unroll
                             for (int j = 0; j < WORDS; j++) acc[b][q] += __builtin_popcount(outw[b][q][j]);
+                    } else if constexpr (RC == 2) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+                            for (int j = 0; j < WORDS; j++) {
+                                c0 += __builtin_popcount(outw[b][2 * q][j]);
+                                c1 += __builtin_popcount(outw[b][2 * q + 1][j]);
+                            }
+                            acc2[pi][b][q] += c0 | (c1 << 16);
+                        }
                     } else if (a.hits && !use_hist) {
                         uint32_t cnt[8];
 #pragma unroll
@@ -1143,9 +1192,18 @@ __global__ __launch_bounds__(kBlockThreads) void shared_wide2_kernel(ScanArgs a)
                     }
                 }
             }
+        };
+        if constexpr (RC == 2) { // two rounds at most, unrolled: the round indexes acc2
+#pragma unroll
+            for (uint32_t pi = 0; pi < 2; pi++)
+                if (pi < npass32) do_round(pi);
+            if (++tiles_counted == kPackedFlushTiles) flush_packed();
+        } else {
+            for (uint32_t pi = 0; pi < npass32; pi++) do_round(pi);
         }
         tile = next;
     }
+    if constexpr (RC == 2) flush_packed();
     if constexpr (reg_counts) {
         // a lane's count is below 2^32 (it sees at most n / 64 values); the wave's sum need not be: reduce in 64 bits
 #pragma unroll
@@ -1435,6 +1493,465 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
         }
     }
     if (a.hits) block_hits_flush(a, s_hits, P);
+    hits_finalize(a, P, lane);
+}
+
+// ---- shared scan, linear layout, any P = 9 .. 1024: full tables in memory order, the short last table on its own ---------
+// shared_linear_kernel above gives every (row, table) pair a lane, the row's last table included even when it holds one
+// key: P = 33 costs two lane-steps per row where P = 32 costs one (2.7 TB/s against 4.1), P = 65 three against two.  The
+// kernel is bound by those lane-steps (VALU: decode, byte regrouping, 8x8 transposes, packed hit counters), not by memory.
+// Here a row is Tf = P / 32 FULL pieces plus, when R = P mod 32 > 0, one SHORT piece of R bytes, and the two kinds never
+// share a step:
+//   * full pieces: lanes (row, table) in memory order as before (lane's table fixed, 64 mod Tf lanes idle);
+//   * the short piece costs what its R keys need -- ceil(R / 8) of the four 8x8 transposes, 3 byte-gather operations instead
+//     of 16 when R <= 8, one or two stores, ceil(R / 4) counters -- and
+//       - Tf = 1 (P = 33 .. 63): the lane that has just done the row's full piece does the short one too, from the values
+//         it already decoded (no second fetch / decode);
+//       - Tf >= 2 or Tf = 0 (P = 9 .. 31): steps of their own with a lane per row (64 rows a step), run as soon as the full
+//         steps have passed their rows, so that both kinds of piece reach a 128-byte line within a few steps of each
+//         other (a tile's rows are 512 P bytes: written a phase apart, the first phase's partly written lines would
+//         leave the L2 before the second one fills them).
+// Piece sizes are wave-uniform in every step, so no lane ever waits for another lane's longer store ladder.
+template <int C, int AUX_>
+__global__ __launch_bounds__(kBlockThreads) void shared_linear2_kernel(ScanArgs a)
+{
+    constexpr int VPL = 64; // tile geometry of the shared scans: 4096 values = 512 rows of 8
+    using G = ScanGeom<C, VPL>;
+    using L = WideLutGeom<C>;
+    constexpr int AUX = AUX_ & 15;
+    constexpr int ROWS = G::TILE_VALUES / 8;
+    constexpr int ROW_DW = (C + 3) / 4;      // dwords holding a row's C bytes once shifted into place
+    constexpr int LOAD_DW = (C + 3 + 3) / 4; // dwords to fetch: the row may start at any byte of a dword
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES + 16];
+    __shared__ uint32_t s_hits[kMaxKeys];
+    constexpr bool HIST = C <= 12; // hit counts by histogram of the values (see shared_wide2_kernel), else packed byte counters
+    __shared__ uint32_t hist[HIST ? (1 << C) : 1];
+    uint32_t *const lut = (uint32_t *)mi355_dyn_lds; // ceil(P/32) tables of TABLE_BYTES
+    for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxKeys; k += kBlockThreads) s_hits[k] = 0;
+    if constexpr (HIST)
+        for (uint32_t k = threadIdx.x; k < (1u << C); k += kBlockThreads) hist[k] = 0;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t P = a.nkeys;
+    const uint32_t Tf = P / 32, R = P % 32;                        // full tables; keys of the short last one
+    const uint32_t T = Tf + (R ? 1u : 0u);
+    const bool attached = Tf == 1 && R != 0;                       // the short piece rides on the full piece's lane
+    const bool dedicated = R != 0 && Tf != 1;                      // ... or gets steps of its own
+    const bool aligned16 = (P & 15u) == 0;                         // every full piece starts on a 16-byte boundary
+    const bool use_hist = HIST && P >= 128;
+
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+    for (uint32_t i = threadIdx.x; i < T * L::TABLE_DWORDS; i += kBlockThreads) lut[i] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) {
+        const uint32_t key = (uint32_t)a.keys_dev[k];
+        const bool in_range = C == 32 || (key >> (C & 31)) == 0;
+        if (in_range) {
+#pragma unroll
+            for (int d = 0; d < L::ND; d++) {
+                const uint32_t e = L::SINGLE ? key : L::digit(key, d);
+                __hip_atomic_fetch_or(lut + (k >> 5) * L::TABLE_DWORDS + d * L::ENTRIES + e, 1u << (k & 31), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+
+    // full pieces: lane l has table l mod Tf and, in step s, row l / Tf + s * (64 / Tf)
+    const uint32_t Tq = Tf ? Tf : 1u;
+    const uint32_t quarter = (uint32_t)lane % Tq;
+    const uint32_t rows_per_step = 64u / Tq;
+    const bool has_table = Tf != 0 && (uint32_t)lane < rows_per_step * Tq;
+    const uint32_t row_first = (uint32_t)lane / Tq;
+    const uint32_t nsteps_full = Tf ? ((uint32_t)ROWS + rows_per_step - 1) / rows_per_step : 0u;
+    const uint32_t *const table_full = lut + (has_table ? quarter : 0u) * L::TABLE_DWORDS;
+    const uint32_t *const table_short = lut + Tf * L::TABLE_DWORDS;
+    // histogram hit counts: the Tf lanes of a row share its values -- value i belongs to the lane of table i mod Tf
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if ((uint32_t)i % Tq == quarter) mine |= 1u << i;
+    // packed per-byte hit counters of a piece's result bytes (at most 8 per step: flushed to the block's LDS counters every
+    // 31 steps, counted ACROSS tiles), one set for the lane's full table, one for the short one
+    uint32_t cbf[8], cbs[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cbf[i] = cbs[i] = 0;
+    uint32_t since_f = 0, since_s = 0;
+    auto flush = [&](uint32_t (&cb)[8], uint32_t first_key, uint32_t &since) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#pragma unroll
+            for (int bq = 0; bq < 4; bq++) {
+                const uint32_t v = (cb[i] >> (8 * bq)) & 0xffu;
+                if (v) atomicAdd(&s_hits[first_key + 4 * i + bq], v); // result dword i of a piece = keys 4 i .. 4 i + 3 of its table
+            }
+            cb[i] = 0;
+        }
+        since = 0;
+    };
+    const bool count_packed = a.hits && !use_hist;
+
+    // the row's C bytes start at byte row * C of the tile: fetch the dwords around them, shift into place, decode 8 values
+    auto fetch = [&](uint32_t row, uint32_t (&x)[8]) {
+        const uint32_t byte0 = row * C;
+        const uint32_t *src = (const uint32_t *)(lds_wave + (byte0 & ~3u));
+        uint32_t d[LOAD_DW];
+#pragma unroll
+        for (int i = 0; i < LOAD_DW; i++) d[i] = src[i];
+        const uint32_t sh = (byte0 & 3u) * 8u;
+        uint32_t w[ROW_DW];
+#pragma unroll
+        for (int i = 0; i < ROW_DW; i++) w[i] = (i + 1 < LOAD_DW) ? __builtin_amdgcn_alignbit(d[i + 1], d[i], sh) : (d[i] >> sh);
+        extract_all<C, 8, 0, ROW_DW>(w, x);
+    };
+    // one piece: 8 lookups in `table`, regroup to key-bytes, 8x8 bit transposes of the key-bytes in use, store, count.
+    // nbytes (1 .. 32) is wave-uniform.
+    auto piece = [&](const uint32_t (&x)[8], const uint32_t *table, uint32_t nbytes, uint32_t nvalid, uint8_t *dst, uint32_t (&cb)[8]) {
+        uint32_t m[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            m[i] = L::lookup(table, x[i]);
+            if ((uint32_t)i >= nvalid) m[i] = 0u;
+        }
+        uint32_t y[8];
+        if (nbytes <= 8u) { // one key-byte: gather the low bytes of the 8 dwords
+            uint32_t lo = __builtin_amdgcn_perm(m[1], m[0], 0x0c0c0400u) | __builtin_amdgcn_perm(m[3], m[2], 0x04000c0cu);
+            uint32_t hi = __builtin_amdgcn_perm(m[5], m[4], 0x0c0c0400u) | __builtin_amdgcn_perm(m[7], m[6], 0x04000c0cu);
+            transpose8x8(lo, hi);
+            y[0] = lo;
+            y[1] = hi;
+#pragma unroll
+            for (int i = 2; i < 8; i++) y[i] = 0;
+        } else {
+            const uint32_t r0[4] = {m[0], m[1], m[2], m[3]}, r1[4] = {m[4], m[5], m[6], m[7]};
+            uint32_t lo4[4], hi4[4];
+            transpose4x4_bytes(r0, lo4);
+            transpose4x4_bytes(r1, hi4);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                uint32_t lo = 0, hi = 0;
+                if (8u * b < nbytes) { // (key-bytes behind the end of a short piece are neither transposed nor counted)
+                    lo = lo4[b], hi = hi4[b];
+                    transpose8x8(lo, hi);
+                }
+                y[2 * b] = lo;
+                y[2 * b + 1] = hi;
+            }
+        }
+        if (nbytes == 32u) {
+            if (aligned16) {
+                ((u32x4 *)dst)[0] = u32x4{y[0], y[1], y[2], y[3]};
+                ((u32x4 *)dst)[1] = u32x4{y[4], y[5], y[6], y[7]};
+            } else {
+                *(Unaligned16 *)dst = Unaligned16{y[0], y[1], y[2], y[3]};
+                *(Unaligned16 *)(dst + 16) = Unaligned16{y[4], y[5], y[6], y[7]};
+            }
+        } else {
+            store_row_piece(dst, y, nbytes);
+        }
+        if (count_packed) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (4u * i < nbytes) {
+                    uint32_t v = y[i];
+                    v = v - ((v >> 1) & 0x55555555u);
+                    v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+                    cb[i] += (v + (v >> 4)) & 0x0F0F0F0Fu;
+                }
+            }
+        }
+    };
+
+    while (tile < tc.ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // rows of the tile that exist (the ragged tile: fewer, the last one possibly with fewer than 8 values)
+        const uint64_t left = tc.n - tile * G::TILE_VALUES;
+        const uint32_t vals_here = left >= (uint64_t)G::TILE_VALUES ? (uint32_t)G::TILE_VALUES : (uint32_t)left;
+        const uint32_t rows_here = (vals_here + 7) / 8;
+        uint8_t *const out_tile = a.out + tile * (uint64_t)ROWS * P;
+        // one step of short pieces: rows [64 j, 64 j + 64), a lane per row
+        auto short_step = [&](uint32_t j) {
+            const uint32_t row = 64u * j + (uint32_t)lane;
+            if (row < rows_here) {
+                uint32_t x[8];
+                fetch(row, x);
+                const uint32_t nvalid = vals_here - row * 8 >= 8u ? 8u : vals_here - row * 8;
+                piece(x, table_short, R, nvalid, out_tile + (uint64_t)row * P + 32u * Tf, cbs);
+            }
+            if (count_packed && ++since_s == 31) flush(cbs, 32u * Tf, since_s);
+        };
+        uint32_t short_done = 0; // 64-row blocks whose short pieces are written
+#pragma unroll 1
+        for (uint32_t s = 0; s < nsteps_full; s++) {
+            const uint32_t row = row_first + s * rows_per_step;
+            if (row < rows_here && has_table) { // (rows beyond the column: nothing is written)
+                uint32_t x[8];
+                fetch(row, x);
+                const uint32_t nvalid = vals_here - row * 8 >= 8u ? 8u : vals_here - row * 8; // short only at the column's end
+                piece(x, table_full, 32u, nvalid, out_tile + (uint64_t)row * P + 32u * quarter, cbf);
+                if (attached) piece(x, table_short, R, nvalid, out_tile + (uint64_t)row * P + 32u, cbs);
+                if (HIST && use_hist && a.hits) {
+                    // (Tf >= 8: one value per lane, picked by a select chain -- one atomic instruction per step)
+                    if (Tf >= 8) {
+                        uint32_t xi = x[0];
+#pragma unroll
+                        for (int i = 1; i < 8; i++) xi = quarter == (uint32_t)i ? x[i] : xi;
+                        if (quarter < 8 && quarter < nvalid)
+                            __hip_atomic_fetch_add(&hist[xi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; i++)
+                            if (((mine >> i) & 1u) && (uint32_t)i < nvalid)
+                                __hip_atomic_fetch_add(&hist[x[i]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            if (count_packed) {
+                if (++since_f == 31) flush(cbf, 32u * quarter, since_f);
+                if (attached && ++since_s == 31) flush(cbs, 32u, since_s);
+            }
+            if (dedicated) { // short pieces of the 64-row blocks the full steps have passed
+                const uint32_t covered = (s + 1) * rows_per_step;
+                while (64u * (short_done + 1) <= covered && short_done < (uint32_t)ROWS / 64u) short_step(short_done++);
+            }
+        }
+        if (dedicated)
+            while (short_done < (uint32_t)ROWS / 64u) short_step(short_done++);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the tile's LDS reads are done: the next DMA may overwrite it
+        const uint64_t next = tile + stride;
+        if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+        tile = next;
+    }
+    if (count_packed) {
+        if (has_table) flush(cbf, 32u * quarter, since_f);
+        if (R != 0) flush(cbs, 32u * Tf, since_s);
+    }
+    if constexpr (HIST) {
+        if (a.hits && use_hist) {
+            __syncthreads(); // every wave's histogram adds are done
+            for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) {
+                const uint32_t key = (uint32_t)a.keys_dev[k];
+                s_hits[k] = (key >> C) == 0 ? hist[key] : 0u; // keys outside [0, 2^C) match nothing
+            }
+        }
+    }
+    if (a.hits) block_hits_flush(a, s_hits, P);
+    hits_finalize(a, P, lane);
+}
+
+// (Round 3 also tried tables kept ALREADY TRANSPOSED -- Entry[v] of 16 keys = 16 bytes, byte j = 1 iff v == key[j], so that a row's
+// result bytes are OR_i Entry[v_i] << i: 16 ds_read_b128 + 64 v_lshl_or_b32 per row and 32 keys instead of 8 ds_read_b32 + ~120
+// VALU operations for regrouping and bit transposes.  It LOSES everywhere: random 16-byte LDS reads run at ~40 cycles per wave
+// instruction (bank conflicts), 8x the read traffic made the LDS the bottleneck -- 2.5e8 x 9 bit, linear, same box, with hit
+// counts: P = 16 3.06 against 4.23 TB/s, P = 64 2.86 against 3.97; profiles/r03_spread_tables_linear_negative.txt.  Removed.)
+
+// ---- shared scan, per-predicate bitmaps, digit-table widths (c > 10): one 32-value word at a time ---------------------------
+// shared_wide2_kernel keeps a lane's 64 decoded values, the 64 result words of a 32-key round and the 32 registers of the
+// transposes live at once: with three or four digits per lookup the compiler needs 256 VGPRs + 60 .. 110 AGPRs for it -- ONE
+// wave per SIMD, every LDS lookup -> AND -> transpose chain exposed (profiles/r03_wide_widths_before.txt: 2.6 .. 3.2 TB/s at
+// c = 17 .. 25, P = 64, waves waiting 40 .. 47 % of their cycles).  Here the word loop is OUTSIDE the rounds: the 32 values
+// of a word are decoded from the lane's raw dwords, and each round's lookups, byte regrouping and register transposes end
+// in the 32 keys' bitmap words of that ONE word, which are counted and stored (4 bytes per lane and key: a wave writes 256
+// contiguous bytes per key) straight from the transposed registers -- half the live state, several waves per SIMD.
+// Hit counts only in registers: RC = 1 (P <= 32, a register per key) or 2 (P <= 64, two keys per register in 16-bit halves,
+// flushed every kPackedFlushTiles tiles); RC = 0 counts nothing (the launcher sends scans WITH hit counts over more than 64
+// keys to shared_wide2_kernel).  BIG: WideLutGeom's wider digits.
+template <int C, int BASE, int N, int K, int NW> __device__ __forceinline__ void extract_range(const uint32_t (&w)[NW], uint32_t (&x)[N])
+{
+    x[K] = extract<C, BASE + K, NW>(w);
+    if constexpr (K + 1 < N) extract_range<C, BASE, N, K + 1, NW>(w, x);
+}
+
+// (waves per SIMD asked of the register allocator: 3 without counters; with them 2 -- at 3 it spilled 90 .. 430 bytes per lane
+// to scratch and the counted scans of c = 21 / 25 ran at 2.2 .. 3.3 TB/s where the uncounted ones reached 4.6 .. 5.4)
+template <int C, int AUX_, int RC, bool BIG>
+__global__ __launch_bounds__(kBlockThreads, (RC == 0 ? 3 : 2)) void shared_wide3_kernel(ScanArgs a)
+{
+    constexpr int VPL = 64;
+    using G = ScanGeom<C, VPL>;
+    using L = WideLutGeom<C, BIG>;
+    constexpr int WORDS = G::WORDS;
+    constexpr int AUX = AUX_ & 15;
+    constexpr int NTS = (AUX_ & 32) ? 2 : ((AUX_ & 16) ? 1 : 0); // result stores: 1 non-temporal, 2 write-through (sc1)
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+    uint32_t *const lut = (uint32_t *)mi355_dyn_lds; // ceil(P/32) * TABLE_BYTES dynamic bytes
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t P = a.nkeys;
+    const uint32_t npass32 = (P + 31) / 32;
+
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+    for (uint32_t i = threadIdx.x; i < npass32 * L::TABLE_DWORDS; i += kBlockThreads) lut[i] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) {
+        const uint32_t key = (uint32_t)a.keys_dev[k];
+        const bool in_range = C == 32 || (key >> (C & 31)) == 0;
+        if (in_range) {
+#pragma unroll
+            for (int d = 0; d < L::ND; d++) {
+                const uint32_t e = L::SINGLE ? key : L::digit(key, d);
+                __hip_atomic_fetch_or(lut + (k >> 5) * L::TABLE_DWORDS + d * L::ENTRIES + e, 1u << (k & 31), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+
+    // RC == 1: acc[0][b][q] = hits of key 8 b + q.  RC == 2: acc[p][b][q], q < 4: keys 32 p + 8 b + 2 q (low half), + 1 (high half)
+    constexpr int NR = RC == 2 ? 2 : 1;
+    uint32_t acc[NR][4][RC == 1 ? 8 : 4];
+#pragma unroll
+    for (int p = 0; p < NR; p++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int q = 0; q < (RC == 1 ? 8 : 4); q++) acc[p][b][q] = 0;
+    uint32_t tiles_counted = 0;
+    auto flush_counts = [&]() {
+        if constexpr (RC != 0) {
+#pragma unroll
+            for (int p = 0; p < NR; p++)
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+#pragma unroll
+                    for (int q = 0; q < (RC == 1 ? 8 : 4); q++) {
+                        // (a lane's count stays below 2^32 / 2^16; the wave's sum need not: two halves)
+                        const uint32_t lo = wave_sum(acc[p][b][q] & 0xffffu), hi = wave_sum(acc[p][b][q] >> 16);
+                        acc[p][b][q] = 0;
+                        if (lane == 0) {
+                            unsigned long long *slot = a.scratch + (blockIdx.x % kHitSlots) * kMaxKeys + 32 * p + 8 * b + (RC == 1 ? q : 2 * q);
+                            if constexpr (RC == 1) {
+                                const unsigned long long v = (unsigned long long)lo + ((unsigned long long)hi << 16);
+                                if (v) __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else {
+                                if (lo) __hip_atomic_fetch_add(slot, (unsigned long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (hi) __hip_atomic_fetch_add(slot + 1, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
+        }
+        tiles_counted = 0;
+    };
+
+    uint32_t behind = 0; // stores issued after the DMA the next wait is for (wait_dma_behind_stores)
+    while (tile < tc.ntiles) {
+        wait_dma_behind_stores(behind);
+        const uint64_t next = tile + stride;
+        const bool full = tile < tc.nfull;
+        // (the tile's first word is stored before the next tile's DMA is issued, its second word behind it)
+        behind = full ? P : 0;
+        const uint64_t tile_left = tc.n - tile * G::TILE_VALUES; // values of the column from the tile's first on
+        uint8_t *const out_tile = a.out + tile * G::BITMAP_BYTES;
+
+        auto do_word = [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            // Phase j: lane l takes the tile's 32-value word 64 j + l -- C whole dwords of the LDS image -- so that the 64
+            // lanes' result words of a key are 256 CONTIGUOUS bytes of its bitmap (two whole lines per store instruction.
+            // A lane owning 64 consecutive values, as everywhere else, would write its two words 4 bytes at a time, 8 bytes
+            // apart: half-written lines, 1.4 TB/s).  The dwords are fetched when the phase's turn comes (all 2 C at once cost
+            // c >= 27 a wave per SIMD); the next tile's DMA may overwrite the tile once the LAST phase's dwords are in registers.
+            const uint32_t word = 64u * j + (uint32_t)lane;
+            const int64_t left = (int64_t)tile_left - (int64_t)word * 32;
+            const int valid = left >= 32 ? 32 : (left <= 0 ? 0 : (int)left); // values of the word inside the column
+            uint8_t *const out_lane = out_tile + word * 4u;
+            uint32_t wj[C];
+            {
+                const uint32_t *src = (const uint32_t *)lds_wave + word * (uint32_t)C;
+#pragma unroll
+                for (int q = 0; q < C; q++) wj[q] = src[q];
+            }
+            if constexpr (j == WORDS - 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+            }
+            uint32_t x[32];
+            extract_range<C, 0, 32, 0, C>(wj, x);
+            auto do_round = [&](const uint32_t pi) __attribute__((always_inline)) {
+                const uint32_t *table = lut + pi * L::TABLE_DWORDS;
+                const uint32_t nb = ((P - pi * 32) < 32 ? (P - pi * 32) + 7 : 39) / 8; // key-bytes in use, 1..4
+                uint32_t R[4][8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    uint32_t r[4], c[4];
+#pragma unroll
+                    for (int Lg = 0; Lg < 4; Lg++) {
+                        const int v = 8 * Lg + i;
+                        uint32_t m = L::lookup(table, x[v]);
+                        if (!full) m = v < valid ? m : 0u; // ragged tile: values >= n contribute nothing
+                        r[Lg] = m;
+                    }
+                    transpose4x4_bytes(r, c); // c[b] byte Lg = key-byte b of value 8 Lg + i
+#pragma unroll
+                    for (int b = 0; b < 4; b++) R[b][i] = c[b];
+                    // (4 x ND lookups in flight are enough: let the scheduler hoist all 32 x ND of a word and the four-digit
+                    // widths need 256 VGPRs + AGPRs again)
+                    if constexpr (L::ND >= 3) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    if ((uint32_t)b < nb) { // wave-uniform
+                        transpose_bits_8regs(R[b]); // R[b][q] = this word of key 32 pi + 8 b + q
+                        if constexpr (RC == 1) {
+#pragma unroll
+                            for (int q = 0; q < 8; q++) acc[0][b][q] += __builtin_popcount(R[b][q]);
+                        } else if constexpr (RC == 2) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++)
+                                acc[pi][b][q] += (uint32_t)__builtin_popcount(R[b][2 * q]) | ((uint32_t)__builtin_popcount(R[b][2 * q + 1]) << 16);
+                        }
+                        uint8_t *dst = out_lane + (uint64_t)(pi * 32 + 8 * b) * a.out_stride;
+                        if (full) {
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                if (pi * 32 + 8 * b + q < P) {
+                                    const uint32_t one[1] = {R[b][q]};
+                                    store_words<1, NTS>(dst, one);
+                                }
+                                dst += a.out_stride;
+                            }
+                        } else {
+                            const int nbytes = (valid + 7) / 8; // the bitmap is written byte-exact
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                if (pi * 32 + 8 * b + q < P) {
+#pragma unroll
+                                    for (int bb = 0; bb < 4; bb++)
+                                        if (bb < nbytes) dst[bb] = (uint8_t)(R[b][q] >> (8 * bb));
+                                }
+                                dst += a.out_stride;
+                            }
+                        }
+                    }
+                }
+            };
+            if constexpr (RC == 2) { // two rounds at most, unrolled: the round indexes acc
+#pragma unroll
+                for (uint32_t pi = 0; pi < 2; pi++)
+                    if (pi < npass32) do_round(pi);
+            } else {
+#pragma unroll 1
+                for (uint32_t pi = 0; pi < npass32; pi++) do_round(pi);
+            }
+        };
+        do_word(std::integral_constant<int, 0>{});
+        do_word(std::integral_constant<int, 1>{});
+        static_assert(WORDS == 2, "two words per lane");
+        if constexpr (RC != 0) {
+            if (++tiles_counted == kPackedFlushTiles) flush_counts();
+        }
+        tile = next;
+    }
+    if constexpr (RC != 0) flush_counts();
     hits_finalize(a, P, lane);
 }
 

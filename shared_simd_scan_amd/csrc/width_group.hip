@@ -185,11 +185,12 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         const bool lin_rows = linear && P > 8 && lut_fits<C, VPL>(P) && !(r.scan.flags & 2u) && lin_pays &&
                               (2 * ((size_t)((P + 31) / 32) * WideLutGeom<C>::TABLE_BYTES + lut_static_lds<C, VPL>()) <= 160 * 1024 ||
                                (r.scan.hits && WideLutGeom<C>::SINGLE));
-        // Per-predicate bitmaps at the widths of three or four table digits with few keys: the compare chain (16 v_cmp + v_addc
-        // per value) beats three or four LDS lookups + ANDs per value at two waves per SIMD (2.5e8 rows, with hit counts, TB/s:
-        // c = 17, P = 16: 3.1 against 2.7; c = 25: 3.4 against 2.5; c = 32: 4.0 against 2.5 and P = 24: 3.4 against 2.8; from
-        // P = 32 on the tables win again; linear rows go to shared_linear_kernel, which beats both).
-        const bool chain_pays = !linear && C >= 17 && P <= (C >= 25 ? 24u : 16u);
+        // Per-predicate bitmaps at the widths of three or four table digits with few keys: round 2 sent them to the compare chain
+        // (16 v_cmp + v_addc per value beat three or four lookups + ANDs per value in shared_wide2_kernel at ONE wave per SIMD).
+        // shared_wide3_kernel turns that around (2.5e8 rows, with hit counts, TB/s, tables against chain: c = 17, P = 16: 4.39
+        // against 2.92; c = 21: 3.61 against 3.27; c = 29: 4.77 against 3.56, P = 24: 4.74), so the chain keeps only the key
+        // counts whose tables do not fit (flags bit 10: round 2's rule, for A/B).
+        const bool chain_pays = !linear && C >= 17 && P <= (C >= 25 ? 24u : 16u) && (r.scan.flags & 0x400u);
         if (r.choice_out) { // introspection (mi355_shared_scan_kernel): which kernel family would run, nothing is launched
             *r.choice_out = (P == 2 && !(r.scan.flags & 32u)) ? 5 : P <= 8 ? 0 : lin_rows ? 4 : (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P)) ? 1 : (lut_fits<C, VPL>(P) && !chain_pays) ? 2 : 3;
             break;
@@ -250,30 +251,99 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 // P = 16: two rows per 32-byte piece only with the digit tables (c > 10: 4.0 / 4.8 TB/s against 3.2 / 4.2 with one
                 // row per piece at c = 12); at c <= 10 one row per piece wins (c = 5: 3.0 / 4.7 against 2.0 / 4.1, c = 9: 3.9 /
                 // 4.8 against 3.5 / 4.9 with / without hit counts).  (flags bit 4: one row per piece everywhere, for A/B)
+                // everything else: full tables in memory order, the short last table on its own (shared_linear2_kernel; flags
+                // bit 8: round 2's kernel, which gives the short table a whole lane per row, for A/B)
                 if (P == 16 && C > 10 && !(r.scan.flags & 16u))
                     hipLaunchKernelGGL((shared_linear_kernel<C, 2, 2>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);
-                else
+                // (2.5e8 x 9 bit, same box, TB/s with / without hit counts, shared_linear2_kernel against shared_linear_kernel:
+                // P = 33: 3.10 / 3.27 against 2.59 / 2.88, P = 40: 3.21 / 3.40 against 2.97 / 3.23, P = 48: 3.26 / 3.49 against
+                // 3.14 / 3.31, P = 63: 2.65 / 2.81 against 2.77 / 2.83; P = 12: 2.87 / 4.09 against 3.43 / 3.77; and the short
+                // table in steps of its own behind two or more full tables LOSES -- P = 100: 2.26 / 2.47 against 3.18 / 3.63,
+                // P = 300: 2.45 / 2.63 against 3.58 / 4.07: a step that writes 4 bytes of each of 64 rows is 64 partial-line
+                // transactions, where the old mapping's short lane sits in the same store instruction as its row's full pieces)
+                else if ((r.scan.flags & 256u) || !((P / 32 == 1 && P % 32 >= 1 && P % 32 <= 24) || (P < 32 && !r.scan.hits)))
                     hipLaunchKernelGGL((shared_linear_kernel<C, 2, 1>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+                else {
+                    allow_dynamic_lds<shared_linear2_kernel<C, 2>>(max_dyn, r.device);
+                    hipLaunchKernelGGL((shared_linear2_kernel<C, 2>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+                }
             } else if (!linear && !(r.scan.flags & 2u)) { // (flags bit 1: the per-group kernel, for A/B)
-                // one 32-key round with hit counts: the counts stay in registers (2.5e8 x 9 bit, same box: P = 16 0.200 -> 0.158 ms,
-                // P = 32 0.298 -> 0.249); single-table widths only -- the digit tables of c > 10 leave no registers for it
-                // (flags bit 3: the per-tile wave reductions, for A/B)
-                auto go = [&](auto regcnt) {
-                    constexpr bool R = decltype(regcnt)::value;
-                    allow_dynamic_lds<shared_wide2_kernel<C, 2, VPL, R>>(max_dyn, r.device);
-                    allow_dynamic_lds<shared_wide2_kernel<C, 18, VPL, R>>(max_dyn, r.device);
-                    if (nt_stores)
-                        hipLaunchKernelGGL((shared_wide2_kernel<C, 18, VPL, R>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
-                    else
-                        hipLaunchKernelGGL((shared_wide2_kernel<C, 2, VPL, R>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
-                };
-                if constexpr (WideLutGeom<C>::SINGLE) {
-                    if (P <= 32 && r.scan.hits && !(r.scan.flags & 8u)) {
-                        go(std::true_type{});
+                // Hit counts in registers (flags bit 3: per-tile wave reductions / the histogram instead, for A/B): one 32-key
+                // round in 32-bit registers (P <= 32: 2.5e8 x 9 bit, same box, P = 16 0.200 -> 0.158 ms, P = 32 0.298 -> 0.249),
+                // two rounds in packed 16-bit halves (P <= 64, round 3: c = 9, P = 33 / 40 / 48 3.50 / 3.96 / 4.12 -> 4.44 / 4.81 /
+                // 4.87 TB/s; not where the histogram counts -- c <= 12, P >= 64: 4.99 against 4.66).
+                // Wider digits (BIG; flags bit 9: byte digits, for A/B) at the widths of three or four byte digits while two
+                // blocks per CU still fit.
+                constexpr bool kBigWidth = (C >= 17 && C <= 20) || (C >= 25 && C <= 30);
+                const bool hist_counts = C <= 12 && P >= 64;
+                const int rc = (r.scan.hits && !(r.scan.flags & 8u)) ? (P <= 32 ? 1 : ((P <= 64 && !hist_counts) ? 2 : 0)) : 0;
+                bool big = false;
+                if constexpr (kBigWidth)
+                    big = !(r.scan.flags & 0x200u) &&
+                          2 * ((size_t)((P + 31) / 32) * WideLutGeom<C, true>::TABLE_BYTES + lut_static_lds<C, VPL>()) <= 160 * 1024;
+                // digit-table widths: a 32-value word at a time (shared_wide3_kernel: half the registers, several waves per
+                // SIMD) for every scan it can count -- without hit counts, or up to 64 keys (flags bit 11: shared_wide2_kernel, A/B)
+                if constexpr (C > 10) {
+                    if ((!r.scan.hits || rc != 0) && !(r.scan.flags & 0x800u)) {
+                        auto go3 = [&](auto rc_c, auto big_c) {
+                            constexpr int RC = decltype(rc_c)::value;
+                            constexpr bool BIG = decltype(big_c)::value;
+                            const size_t bdyn = (size_t)((P + 31) / 32) * WideLutGeom<C, BIG>::TABLE_BYTES;
+                            allow_dynamic_lds<shared_wide3_kernel<C, 2, RC, BIG>>(max_dyn, r.device);
+                            allow_dynamic_lds<shared_wide3_kernel<C, 18, RC, BIG>>(max_dyn, r.device);
+                            const size_t per_block = bdyn + 4 * ScanGeom<C, 64>::LDS_BYTES + 256;
+                            int fit = (int)((160 * 1024) / per_block);
+                            fit = fit > (RC == 0 ? 3 : 2) ? (RC == 0 ? 3 : 2) : (fit < 1 ? 1 : fit);
+                            const dim3 g3(grid_for(ntiles, r.max_blocks_per_cu > 0 && r.max_blocks_per_cu < fit ? r.max_blocks_per_cu : fit, r.num_cus));
+                            if (nt_stores)
+                                hipLaunchKernelGGL((shared_wide3_kernel<C, 18, RC, BIG>), g3, dim3(kBlockThreads), bdyn, r.stream, r.scan);
+                            else
+                                hipLaunchKernelGGL((shared_wide3_kernel<C, 2, RC, BIG>), g3, dim3(kBlockThreads), bdyn, r.stream, r.scan);
+                        };
+                        auto with_big3 = [&](auto rc_c) {
+                            if constexpr (kBigWidth) {
+                                if (big) {
+                                    go3(rc_c, std::true_type{});
+                                    return;
+                                }
+                            }
+                            go3(rc_c, std::false_type{});
+                        };
+                        if (rc == 1)
+                            with_big3(std::integral_constant<int, 1>{});
+                        else if (rc == 2)
+                            with_big3(std::integral_constant<int, 2>{});
+                        else
+                            with_big3(std::integral_constant<int, 0>{});
                         break;
                     }
                 }
-                go(std::false_type{});
+                auto go = [&](auto rc_c, auto big_c) {
+                    constexpr int RC = decltype(rc_c)::value;
+                    constexpr bool BIG = decltype(big_c)::value;
+                    const size_t bdyn = (size_t)((P + 31) / 32) * WideLutGeom<C, BIG>::TABLE_BYTES;
+                    allow_dynamic_lds<shared_wide2_kernel<C, 2, VPL, RC, BIG>>(max_dyn, r.device);
+                    allow_dynamic_lds<shared_wide2_kernel<C, 18, VPL, RC, BIG>>(max_dyn, r.device);
+                    if (nt_stores)
+                        hipLaunchKernelGGL((shared_wide2_kernel<C, 18, VPL, RC, BIG>), grid, dim3(kBlockThreads), bdyn, r.stream, r.scan);
+                    else
+                        hipLaunchKernelGGL((shared_wide2_kernel<C, 2, VPL, RC, BIG>), grid, dim3(kBlockThreads), bdyn, r.stream, r.scan);
+                };
+                // (register counters in shared_wide2_kernel only at the single-table widths: the digit-table widths that come here
+                // -- more than 64 keys with hit counts, or the A/B switch -- have no registers to spare for them)
+                if (rc == 1 && C <= 10)
+                    go(std::integral_constant<int, (C <= 10 ? 1 : 0)>{}, std::false_type{});
+                else if (rc == 2 && C <= 10)
+                    go(std::integral_constant<int, (C <= 10 ? 2 : 0)>{}, std::false_type{});
+                else {
+                    if constexpr (kBigWidth) {
+                        if (big) {
+                            go(std::integral_constant<int, 0>{}, std::true_type{});
+                            break;
+                        }
+                    }
+                    go(std::integral_constant<int, 0>{}, std::false_type{});
+                }
             } else if (linear)
                 hipLaunchKernelGGL((shared_wide_kernel<C, 2, VPL, 1>), grid, dim3(kBlockThreads), dyn, r.stream, r.scan);
             else if (nt_stores)

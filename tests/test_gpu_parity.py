@@ -1045,15 +1045,17 @@ def test_scan_select_beside_another_contexts_long_kernels(O):
     n, c = 1_000_000_000, 9
     sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
     A, B = ScanEngine(0, stream=sA), ScanEngine(0, stream=sB)
-    col = A.generate("splitmix", n, c, 42)
-    key = int(O.gen_values("splitmix", 1, c, 42, first=12345)[0])
     refs = []
-    for op, x in (("==", key), ("<", 256)):
-        bm, hits = A.scan_where(op, x, col)
-        h = int(hits.item())
-        ids_ref, _ = A.bitmap_to_rowids(bm, n, capacity=h)
-        refs.append((op, x, h, ids_ref))
-        del bm
+    with torch.cuda.stream(sA):  # (allocations and .item() follow the current stream: make it A's)
+        col = A.generate("splitmix", n, c, 42)
+        key = int(O.gen_values("splitmix", 1, c, 42, first=12345)[0])
+        for op, x in (("==", key), ("<", 256)):
+            bm, hits = A.scan_where(op, x, col)
+            h = int(hits.item())
+            ids_ref, _ = A.bitmap_to_rowids(bm, n, capacity=h)
+            refs.append((op, x, h, ids_ref))
+            sA.synchronize()
+            del bm
     torch.cuda.synchronize()
     P = 64
     keys = [(37 * k + 3) % 512 for k in range(P)]
@@ -1062,15 +1064,20 @@ def test_scan_select_beside_another_contexts_long_kernels(O):
     torch.cuda.synchronize()
     for rep in range(4):
         for op, x, h, ids_ref in refs:
-            for _ in range(3):  # ~3 ms each on stream B: the selection below is enqueued while these run
-                B.shared_scan(keys, col, out=out, hits=False)
-            ids, cnt = A.scan_select(op, x, col, capacity=h)
-            for _ in range(2):
-                B.shared_scan(keys, col, out=out, hits=False)
+            with torch.cuda.stream(sB):
+                for _ in range(3):  # ~3 ms each on stream B: the selection below is enqueued while these run
+                    B.shared_scan(keys, col, out=out, hits=False)
+            with torch.cuda.stream(sA):
+                ids, cnt = A.scan_select(op, x, col, capacity=h)
+            with torch.cuda.stream(sB):
+                for _ in range(2):
+                    B.shared_scan(keys, col, out=out, hits=False)
             sA.synchronize()
-            k = int(cnt.item())
-            assert k == h, (op, rep, k, h)
-            assert torch.equal(ids[:h], ids_ref[:h]), (op, rep)
+            with torch.cuda.stream(sA):
+                k = int(cnt.item())
+                assert k == h, (op, rep, k, h)
+                assert torch.equal(ids[:h], ids_ref[:h]), (op, rep)
+            sA.synchronize()
             del ids
     torch.cuda.synchronize()
     del out, col, refs
