@@ -1767,10 +1767,11 @@ template <int C, int BASE, int N, int K, int NW> __device__ __forceinline__ void
     if constexpr (K + 1 < N) extract_range<C, BASE, N, K + 1, NW>(w, x);
 }
 
-// (waves per SIMD asked of the register allocator: 3 without counters; with them 2 -- at 3 it spilled 90 .. 430 bytes per lane
-// to scratch and the counted scans of c = 21 / 25 ran at 2.2 .. 3.3 TB/s where the uncounted ones reached 4.6 .. 5.4)
+// (waves per SIMD asked of the register allocator: 3 without counters and at the single-table widths; with counters at the
+// digit-table widths 2 -- at 3 it spilled 90 .. 430 bytes per lane to scratch and the counted scans of c = 21 / 25 ran at
+// 2.2 .. 3.3 TB/s where the uncounted ones reached 4.6 .. 5.4)
 template <int C, int AUX_, int RC, bool BIG>
-__global__ __launch_bounds__(kBlockThreads, (RC == 0 ? 3 : 2)) void shared_wide3_kernel(ScanArgs a)
+__global__ __launch_bounds__(kBlockThreads, ((RC == 0 || C <= 10) ? 3 : 2)) void shared_wide3_kernel(ScanArgs a)
 {
     constexpr int VPL = 64;
     using G = ScanGeom<C, VPL>;
@@ -1933,6 +1934,232 @@ __global__ __launch_bounds__(kBlockThreads, (RC == 0 ? 3 : 2)) void shared_wide3
                         }
                     }
                 }
+            };
+            if constexpr (RC == 2) { // two rounds at most, unrolled: the round indexes acc
+#pragma unroll
+                for (uint32_t pi = 0; pi < 2; pi++)
+                    if (pi < npass32) do_round(pi);
+            } else {
+#pragma unroll 1
+                for (uint32_t pi = 0; pi < npass32; pi++) do_round(pi);
+            }
+        };
+        do_word(std::integral_constant<int, 0>{});
+        do_word(std::integral_constant<int, 1>{});
+        static_assert(WORDS == 2, "two words per lane");
+        if constexpr (RC != 0) {
+            if (++tiles_counted == kPackedFlushTiles) flush_counts();
+        }
+        tile = next;
+    }
+    if constexpr (RC != 0) flush_counts();
+    hits_finalize(a, P, lane);
+}
+
+// ---- shared scan, linear layout, P = 9 .. 64: the per-predicate machinery + an LDS stage ---------------------------------
+// shared_linear_kernel gives a lane one row of 8 values and pays, per row and 32 keys, 16 v_perm_b32 and four 8x8 bit
+// transposes in register pairs (~25 operations each) plus packed byte counters: 34 VALU operations per value and 32 keys,
+// VALU-bound at 3-4 TB/s (profiles/r03_shared_linear_c9_profile.txt).  The per-predicate kernels get the same bits for ~20:
+// a lane takes a whole 32-value word, the eight-register transposes handle 32 values x 8 keys in 72 operations, and the
+// hit counts are one v_bcnt per key word.  This kernel does exactly that (the body of shared_wide3_kernel: phase j, lane l
+// = the tile's word 64 j + l = rows 4 (64 j + l) .. + 3) and THEN turns the 32 key words of a round back into the rows'
+// bytes: eight 4x4 byte transposes (64 v_perm_b32 per 32 values x 32 keys) give every one of the lane's four rows its 32
+// bytes of the round, which go to a wave-private LDS stage of 256 rows x 32 bytes and leave it in row order -- consecutive
+// lanes write consecutive 16-byte units of the output, 1 KiB per store instruction at P = 32 -- however P relates to 16.
+// The stage's 16-byte units are XOR-swizzled (unit u lives at u ^ ((u >> 3) & 15)): both the writers (lane l: units
+// 8 l + 2 r + h) and the readers (lane i: units i + 64 s) then spread over the 16 unit positions of the LDS's 64 banks four
+// lanes apiece, which is the minimum for 16-byte accesses.
+template <int C, int AUX_, int RC, bool BIG>
+__global__ __launch_bounds__(kBlockThreads, 2) void shared_linear3_kernel(ScanArgs a)
+{
+    constexpr int VPL = 64;
+    using G = ScanGeom<C, VPL>;
+    using L = WideLutGeom<C, BIG>;
+    constexpr int WORDS = G::WORDS;
+    constexpr int AUX = AUX_ & 15;
+    constexpr int STAGE_ROWS = 256; // rows of a phase: 64 lanes x 4
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) u32x4 stage_all[kWavesPerBlock][STAGE_ROWS * 2]; // 32 bytes per row
+    uint32_t *const lut = (uint32_t *)mi355_dyn_lds; // ceil(P/32) * TABLE_BYTES dynamic bytes
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *lds_wave = lds[wave];
+    u32x4 *const stage = stage_all[wave];
+    const TileCtx<C, VPL> tc(a.n);
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t tile = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t P = a.nkeys;
+    const uint32_t npass32 = (P + 31) / 32;
+    const bool aligned16 = (P & 15u) == 0;
+
+    if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
+    for (uint32_t i = threadIdx.x; i < npass32 * L::TABLE_DWORDS; i += kBlockThreads) lut[i] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < P; k += kBlockThreads) {
+        const uint32_t key = (uint32_t)a.keys_dev[k];
+        const bool in_range = C == 32 || (key >> (C & 31)) == 0;
+        if (in_range) {
+#pragma unroll
+            for (int d = 0; d < L::ND; d++) {
+                const uint32_t e = L::SINGLE ? key : L::digit(key, d);
+                __hip_atomic_fetch_or(lut + (k >> 5) * L::TABLE_DWORDS + d * L::ENTRIES + e, 1u << (k & 31), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+
+    // hit counts in registers, as in shared_wide3_kernel
+    constexpr int NR = RC == 2 ? 2 : 1;
+    uint32_t acc[NR][4][RC == 1 ? 8 : 4];
+#pragma unroll
+    for (int p = 0; p < NR; p++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int q = 0; q < (RC == 1 ? 8 : 4); q++) acc[p][b][q] = 0;
+    uint32_t tiles_counted = 0;
+    auto flush_counts = [&]() {
+        if constexpr (RC != 0) {
+#pragma unroll
+            for (int p = 0; p < NR; p++)
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+#pragma unroll
+                    for (int q = 0; q < (RC == 1 ? 8 : 4); q++) {
+                        const uint32_t lo = wave_sum(acc[p][b][q] & 0xffffu), hi = wave_sum(acc[p][b][q] >> 16);
+                        acc[p][b][q] = 0;
+                        if (lane == 0) {
+                            unsigned long long *slot = a.scratch + (blockIdx.x % kHitSlots) * kMaxKeys + 32 * p + 8 * b + (RC == 1 ? q : 2 * q);
+                            if constexpr (RC == 1) {
+                                const unsigned long long v = (unsigned long long)lo + ((unsigned long long)hi << 16);
+                                if (v) __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else {
+                                if (lo) __hip_atomic_fetch_add(slot, (unsigned long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (hi) __hip_atomic_fetch_add(slot + 1, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
+        }
+        tiles_counted = 0;
+    };
+    auto swz = [](uint32_t u) -> uint32_t { return u ^ ((u >> 3) & 15u); };
+
+    while (tile < tc.ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t next = tile + stride;
+        const bool full = tile < tc.nfull;
+        const uint64_t tile_left = tc.n - tile * G::TILE_VALUES; // values of the column from the tile's first on
+        uint8_t *const out_tile = a.out + tile * (uint64_t)(G::TILE_VALUES / 8) * P;
+
+        auto do_word = [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const uint32_t word = 64u * j + (uint32_t)lane;
+            const int64_t left = (int64_t)tile_left - (int64_t)word * 32;
+            const int valid = left >= 32 ? 32 : (left <= 0 ? 0 : (int)left); // values of the word inside the column
+            // rows of this phase that exist (ragged tile: fewer, the last one possibly with fewer than 8 values)
+            const int64_t phase_left = (int64_t)tile_left - (int64_t)j * (STAGE_ROWS * 8);
+            const uint32_t rows_here = phase_left >= STAGE_ROWS * 8 ? (uint32_t)STAGE_ROWS : (phase_left <= 0 ? 0u : (uint32_t)((phase_left + 7) / 8));
+            uint8_t *const out_phase = out_tile + (uint64_t)j * STAGE_ROWS * P;
+            uint32_t wj[C];
+            {
+                const uint32_t *src = (const uint32_t *)lds_wave + word * (uint32_t)C;
+#pragma unroll
+                for (int q = 0; q < C; q++) wj[q] = src[q];
+            }
+            if constexpr (j == WORDS - 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
+            }
+            uint32_t x[32];
+            extract_range<C, 0, 32, 0, C>(wj, x);
+            auto do_round = [&](const uint32_t pi) __attribute__((always_inline)) {
+                const uint32_t *table = lut + pi * L::TABLE_DWORDS;
+                const uint32_t nk = (P - pi * 32) < 32 ? (P - pi * 32) : 32; // keys of this round
+                const uint32_t nb = (nk + 7) / 8;                            // key-bytes in use, 1..4
+                uint32_t R[4][8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    uint32_t r[4], c[4];
+#pragma unroll
+                    for (int Lg = 0; Lg < 4; Lg++) {
+                        const int v = 8 * Lg + i;
+                        uint32_t m = L::lookup(table, x[v]);
+                        if (!full) m = v < valid ? m : 0u; // ragged tile: values >= n contribute nothing
+                        r[Lg] = m;
+                    }
+                    transpose4x4_bytes(r, c); // c[b] byte Lg = key-byte b of value 8 Lg + i
+#pragma unroll
+                    for (int b = 0; b < 4; b++) R[b][i] = c[b];
+                    if constexpr (L::ND >= 3) __builtin_amdgcn_sched_barrier(0);
+                }
+                // the stage must be free: the previous round's copy-out reads are done (LDS is in order per wave, and those
+                // reads were waited for before their stores were issued)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if ((uint32_t)(2 * h) < nb) { // wave-uniform
+                        uint32_t lo[2][4], hi[2][4]; // [key-byte of the half][row]: bytes of keys 8 b .. + 3 / + 4 .. + 7
+#pragma unroll
+                        for (int bb = 0; bb < 2; bb++) {
+                            const int b = 2 * h + bb;
+                            if ((uint32_t)b < nb) {
+                                transpose_bits_8regs(R[b]); // R[b][q] = this word of key 32 pi + 8 b + q: byte r = row r
+                                if constexpr (RC == 1) {
+#pragma unroll
+                                    for (int q = 0; q < 8; q++) acc[0][b][q] += __builtin_popcount(R[b][q]);
+                                } else if constexpr (RC == 2) {
+#pragma unroll
+                                    for (int q = 0; q < 4; q++)
+                                        acc[pi][b][q] += (uint32_t)__builtin_popcount(R[b][2 * q]) | ((uint32_t)__builtin_popcount(R[b][2 * q + 1]) << 16);
+                                }
+                                const uint32_t r0[4] = {R[b][0], R[b][1], R[b][2], R[b][3]}, r1[4] = {R[b][4], R[b][5], R[b][6], R[b][7]};
+                                transpose4x4_bytes(r0, lo[bb]); // lo[bb][r] byte q = row r's byte of key 8 b + q
+                                transpose4x4_bytes(r1, hi[bb]);
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) lo[bb][r] = hi[bb][r] = 0;
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            stage[swz(8u * lane + 2u * r + h)] = u32x4{lo[0][r], hi[0][r], lo[1][r], hi[1][r]};
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's stage writes have landed
+                if (nk == 32u) {
+                    // row order: lane i takes the 16-byte units i + 64 s; unit u = half (u & 1) of row u >> 1
+                    uint8_t *dst = out_phase + (uint64_t)((uint32_t)lane >> 1) * P + 32u * pi + 16u * ((uint32_t)lane & 1u);
+                    const uint64_t step = 32ull * P;
+#pragma unroll
+                    for (int sb = 0; sb < 8; sb += 4) {
+                        u32x4 v[4];
+#pragma unroll
+                        for (int s = 0; s < 4; s++) v[s] = stage[swz((uint32_t)lane + 64u * (sb + s))];
+#pragma unroll
+                        for (int s = 0; s < 4; s++) {
+                            if (((uint32_t)lane >> 1) + 32u * (sb + s) < rows_here) {
+                                if (aligned16)
+                                    *(u32x4 *)dst = v[s];
+                                else
+                                    *(Unaligned16 *)dst = Unaligned16{v[s].x, v[s].y, v[s].z, v[s].w};
+                            }
+                            dst += step;
+                        }
+                    }
+                } else {
+                    // the short last round: a lane per row, nk bytes each
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const uint32_t row = (uint32_t)lane + 64u * s;
+                        const u32x4 v0 = stage[swz(2u * row)];
+                        u32x4 v1 = u32x4{0, 0, 0, 0};
+                        if (nk > 16u) v1 = stage[swz(2u * row + 1u)];
+                        const uint32_t y[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                        if (row < rows_here) store_row_piece(out_phase + (uint64_t)row * P + 32u * pi, y, nk);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // stage reads done before the next round overwrites it
             };
             if constexpr (RC == 2) { // two rounds at most, unrolled: the round indexes acc
 #pragma unroll

@@ -227,6 +227,47 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 }
             }
             launch_lut8<C, 64>(r, P, linear);
+        } else if (linear && P >= 32 && P <= 40 && !(r.scan.flags & 0x2000u) &&
+                   2 * ((size_t)((P + 31) / 32) * WideLutGeom<C, false>::TABLE_BYTES + 4 * ScanGeom<C, 64>::LDS_BYTES + 33 * 1024) <= 160 * 1024) {
+            // linear rows of 32 .. 40 keys: the per-predicate machinery + an LDS stage (shared_linear3_kernel; flags bit 13: the
+            // row-per-lane kernels below, for A/B).  Hit counts in registers: one round (P <= 32) or two packed.  Where it pays
+            // (2.5e8 rows, TB/s with hit counts, against the row-per-lane kernels on the same box): c = 9, P = 32 / 33 / 40:
+            // 4.67 / 3.54 / 3.52 against 4.05 / 3.29 / 3.24; c = 5, P = 32: 4.49 against 3.28; c = 12: 4.54 against 4.06; c = 17:
+            // 4.64 against 4.32.  Where it does not: fewer keys (no VALU to save: P = 9 2.55 against 2.92, P = 16 3.94 against
+            // 4.33, P = 24 / 31 equal), a long second round (its 32-byte pieces complete the first round's half-written lines a
+            // whole round later: P = 48 3.01 against 3.41, P = 64 2.29 against 3.94), and widths whose tiles leave room for one
+            // block per CU only (c = 25, P = 32: 2.95 against 4.40).
+            constexpr bool kBigWidth = (C >= 17 && C <= 20) || (C >= 25 && C <= 30);
+            const int rc = r.scan.hits ? (P <= 32 ? 1 : 2) : 0;
+            const size_t fixed = 4 * ScanGeom<C, 64>::LDS_BYTES + 33 * 1024;
+            bool big = false;
+            if constexpr (kBigWidth)
+                big = !(r.scan.flags & 0x200u) && 2 * ((size_t)((P + 31) / 32) * WideLutGeom<C, true>::TABLE_BYTES + fixed) <= 160 * 1024;
+            auto go3 = [&](auto rc_c, auto big_c) {
+                constexpr int RC = decltype(rc_c)::value;
+                constexpr bool BIG = decltype(big_c)::value;
+                const size_t bdyn = (size_t)((P + 31) / 32) * WideLutGeom<C, BIG>::TABLE_BYTES;
+                allow_dynamic_lds<shared_linear3_kernel<C, 2, RC, BIG>>((int)(160 * 1024 - fixed), r.device);
+                int fit = (int)((160 * 1024) / (bdyn + fixed));
+                fit = fit > 2 ? 2 : (fit < 1 ? 1 : fit);
+                const dim3 g3(grid_for(ntiles, r.max_blocks_per_cu > 0 && r.max_blocks_per_cu < fit ? r.max_blocks_per_cu : fit, r.num_cus));
+                hipLaunchKernelGGL((shared_linear3_kernel<C, 2, RC, BIG>), g3, dim3(kBlockThreads), bdyn, r.stream, r.scan);
+            };
+            auto with_big3 = [&](auto rc_c) {
+                if constexpr (kBigWidth) {
+                    if (big) {
+                        go3(rc_c, std::true_type{});
+                        return;
+                    }
+                }
+                go3(rc_c, std::false_type{});
+            };
+            if (rc == 1)
+                with_big3(std::integral_constant<int, 1>{});
+            else if (rc == 2)
+                with_big3(std::integral_constant<int, 2>{});
+            else
+                with_big3(std::integral_constant<int, 0>{});
         } else if (linear && !r.scan.hits && P < 192 && lut8_fits<C, VPL>(P) && !lin_rows) {
             // linear rows of fewer than ~200 keys without hit counts: byte-entry tables, 16 output bytes per round
             // (measured, tools/sweep_p.py, 2.5e8 x 9 bit: P = 16 / 32 / 64 / 128 0.21 / 0.43 / 0.72 / 1.45 ms against
@@ -281,9 +322,11 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 if constexpr (kBigWidth)
                     big = !(r.scan.flags & 0x200u) &&
                           2 * ((size_t)((P + 31) / 32) * WideLutGeom<C, true>::TABLE_BYTES + lut_static_lds<C, VPL>()) <= 160 * 1024;
-                // digit-table widths: a 32-value word at a time (shared_wide3_kernel: half the registers, several waves per
-                // SIMD) for every scan it can count -- without hit counts, or up to 64 keys (flags bit 11: shared_wide2_kernel, A/B)
-                if constexpr (C > 10) {
+                // a 32-value word at a time (shared_wide3_kernel: half the registers, several waves per SIMD -- what the digit-table
+                // widths need, and 0-20 % ahead at c <= 10 too: 2.5e8 x 9 bit, P = 9 / 24 / 63, TB/s with / without hit counts:
+                // 3.63 / 4.41, 5.13 / 5.43, 5.21 / 5.56 against 3.44 / 3.58, 4.49 / 4.58, 4.39 / 4.49) for every scan it can count:
+                // without hit counts, or up to 64 keys (flags bit 11: shared_wide2_kernel, A/B)
+                {
                     if ((!r.scan.hits || rc != 0) && !(r.scan.flags & 0x800u)) {
                         auto go3 = [&](auto rc_c, auto big_c) {
                             constexpr int RC = decltype(rc_c)::value;
@@ -293,7 +336,8 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                             allow_dynamic_lds<shared_wide3_kernel<C, 18, RC, BIG>>(max_dyn, r.device);
                             const size_t per_block = bdyn + 4 * ScanGeom<C, 64>::LDS_BYTES + 256;
                             int fit = (int)((160 * 1024) / per_block);
-                            fit = fit > (RC == 0 ? 3 : 2) ? (RC == 0 ? 3 : 2) : (fit < 1 ? 1 : fit);
+                            constexpr int kWaves = (RC == 0 || C <= 10) ? 3 : 2; // the kernel's launch bound
+                            fit = fit > kWaves ? kWaves : (fit < 1 ? 1 : fit);
                             const dim3 g3(grid_for(ntiles, r.max_blocks_per_cu > 0 && r.max_blocks_per_cu < fit ? r.max_blocks_per_cu : fit, r.num_cus));
                             if (nt_stores)
                                 hipLaunchKernelGGL((shared_wide3_kernel<C, 18, RC, BIG>), g3, dim3(kBlockThreads), bdyn, r.stream, r.scan);
