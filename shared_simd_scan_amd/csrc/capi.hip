@@ -130,7 +130,7 @@ int launch(mi355_ctx *ctx, LaunchReq &r)
     // option and arrive as its bits 1-4: two TIMING ablations (2 no expansion, 4 no look-back: wrong ids by construction) and
     // two A/B switches of the chunk hand-out (8 chunks dealt out by block index as in round 2, 16 no barrier per generation)
     // (option bits 13.. = further switches of the shared scans; they arrive as their bits 9..)
-    r.scan.flags = r.op == kOpSelect ? ((ctx->kernel_flags >> 8) & 0x1eu) : ((ctx->kernel_flags & 0x1ffu) | ((ctx->kernel_flags >> 4) & 0x3e00u));
+    r.scan.flags = r.op == kOpSelect ? ((ctx->kernel_flags >> 8) & 0x7eu) : ((ctx->kernel_flags & 0x1ffu) | ((ctx->kernel_flags >> 4) & 0x3e00u));
     r.scan.scratch = ctx->kernel_scratch;
     if (r.max_blocks_per_cu == 0 && !ctx->tuned_bpc.empty()) {
         const bool scan = r.op == kOpScanEq || r.op == kOpScanRange;
@@ -313,6 +313,8 @@ int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value)
         ctx->scan_nt_stores = value;
     else if (!strcmp(name, "shared_vpl"))
         ctx->shared_vpl = value;
+    else if (!strcmp(name, "select_kernel"))
+        ctx->select_kernel = value;
     else if (!strcmp(name, "scan_burst"))
         ctx->scan_burst = value;
     else if (!strcmp(name, "kernel_flags"))
@@ -712,6 +714,19 @@ int mi355_scan_select_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, un
     r.scan.capacity = capacity;
     r.scan.first_row = first_row;
     fill_predicate(r.scan, c, op, a, b);
+    // Which kernel: select_kernel (one wave does everything in turn) is 8 % ahead when few rows qualify, select2_kernel
+    // (decoder + expander waves) 1.2 - 2.5 x ahead when many do (1e9 x 9 bit: 0.28 against 0.30 ms at 1/512; 0.39 / 1.20 / 1.47
+    // against 0.32 / 0.47 / 1.07 ms at 1/64, 1/8, 1/2).  The count is not known before the launch: go by the fraction of the value
+    // range the predicate accepts (what it selects of uniformly distributed values) -- at most 1/128: the single-role kernel.
+    // A wrong guess costs time, never the result.  Option "select_kernel": 0 this rule, 1 / 2 force.
+    {
+        const double range = c >= 32 ? 4294967296.0 : (double)(1ull << c);
+        double frac = ((double)r.scan.key[1] + 1.0) / range; // accepted span (fill_predicate: key[1] = hi - lo)
+        if (r.scan.key[0] == 0xffffffffu && r.scan.key[1] == 0 && c < 32) frac = 0.0; // the empty predicate
+        if (r.scan.invert) frac = 1.0 - frac;
+        if (mask_dev && mask_op != MI355_BITMAP_AND && mask_op != MI355_BITMAP_ANDNOT) frac = 1.0; // OR / XOR with an unknown bitmap
+        r.select_single = ctx->select_kernel == 1 || (ctx->select_kernel == 0 && frac <= 1.0 / 128.0);
+    }
     return launch(ctx, r);
 }
 

@@ -19,6 +19,7 @@ struct mi355_ctx {
     int max_blocks_per_cu = 0;
     int scan_nt_stores = -1; // -1: by bitmap size (see width_group.hip), 0 plain, 1 non-temporal
     int shared_vpl = 0;  // 0: engine's choice
+    int select_kernel = 0; // mi355_scan_select_dev: 0 = by the predicate's expected selectivity, 1 = single-role kernel, 2 = decoder / expander roles
     unsigned kernel_flags = 0; // experiment switches handed to the kernels (ScanArgs::flags)
     // mi355_tune_dev: blocks per CU measured on THIS device for the large streaming launches; key = tune_key() in capi.hip
     std::map<uint32_t, int> tuned_bpc;

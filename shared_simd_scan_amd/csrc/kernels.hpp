@@ -21,7 +21,8 @@
 //                          shared scan for P > 8: dword-entry tables, 32 predicates per lookup
 //   shared_general_kernel  shared scan by compare chain, for key counts whose tables do not fit in LDS
 //   in_kernel              IN-list scan (one bitmap for a key set)
-//   select_kernel          predicate -> ascending row ids in one launch (decoupled look-back over chunk counts), no bitmap
+//   select2_kernel         predicate -> ascending row ids in one launch (decoder + expander waves, decoupled look-back over chunk
+//                          counts), no bitmap; select_kernel: round 2's single-role form, kept for A/B
 //   decompress_kernel      packed -> int32, lane per value
 //   pack_kernel            packer and synthetic column generators
 //   bitmap_kernel, rowid_* bitmap combine / count, selection vector
@@ -38,6 +39,7 @@
 #include "kernels/shared.hpp"
 #include "kernels/in_list.hpp"
 #include "kernels/select.hpp"
+#include "kernels/select2.hpp"
 #include "kernels/bitmap.hpp"
 #include "kernels/decompress.hpp"
 #include "kernels/pack.hpp"

@@ -427,7 +427,11 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
         using G = ScanGeom<C, VPL>;
         const uint64_t ntiles = (r.scan.n + G::TILE_VALUES - 1) / G::TILE_VALUES;
         const uint64_t nchunks = (ntiles + select_tiles(C) - 1) / select_tiles(C);
-        hipLaunchKernelGGL((select_kernel<C, kModeRange, VPL>), dim3(grid_for(nchunks, 1, r.num_cus)), dim3(kBlockThreads), 0, r.stream, r.scan);
+        // (flags bit 5 = option bit 13: round 2's single-role kernel, for A/B)
+        if ((r.scan.flags & 32u) || r.select_single)
+            hipLaunchKernelGGL((select_kernel<C, kModeRange, VPL>), dim3(grid_for(nchunks, 1, r.num_cus)), dim3(kBlockThreads), 0, r.stream, r.scan);
+        else
+            hipLaunchKernelGGL((select2_kernel<C, kModeRange, VPL>), dim3(grid_for(nchunks, 1, r.num_cus)), dim3(kSel2Waves * 64), 0, r.stream, r.scan);
         break;
     }
     case kOpScan2: {

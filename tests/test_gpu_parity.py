@@ -1004,6 +1004,16 @@ def test_scan_select_matches_numpy(O, eng, c, n):
     v = vals.astype(np.int64)
     vmax = (1 << c) - 1
     a = int(vals[n // 2])
+    # both kernels behind the entry point whatever the predicate's expected selectivity would pick: option select_kernel
+    # 1 = single-role (select_kernel), 2 = decoder / expander roles (select2_kernel); 0 = the engine's rule again at the end
+    for forced in (1, 2):
+        eng.set_option("select_kernel", forced)
+        for op, x, y, expect in (("==", a, 0, v == a), ("<=", vmax // 2, 0, v <= vmax // 2), ("<", vmax // 8 + 2, 0, v < vmax // 8 + 2)):
+            ids, cnt = eng.scan_select(op, x, col, capacity=n, b=y, first_row=7)
+            want = np.nonzero(expect)[0].astype(np.int64) + 7
+            k = int(cnt.item())
+            assert k == want.shape[0] and np.array_equal(ids[:k].cpu().numpy(), want), (forced, op, c, n)
+    eng.set_option("select_kernel", 0)
     # (selectivities 1/2 and ~1: tiles expanded 64 rows at a time from the registers; ~1/8 .. 1/64: through the LDS
     # stage; a single key: mostly sparse tiles written straight from the lanes)
     for op, x, y, expect in (("==", a, 0, v == a), ("<=", vmax // 2, 0, v <= vmax // 2), ("!=", a, 0, v != a),
