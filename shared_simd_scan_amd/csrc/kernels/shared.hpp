@@ -1307,6 +1307,13 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
     constexpr int LOAD_DW = (RB + 3 + 3) / 4; // dwords to fetch: the piece may start at any byte of a dword
     constexpr int KB = 4 / RP;                // key-bytes (8 keys each) per row inside a piece
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][G::LDS_BYTES + 16];
+    // Rows whose length is not a multiple of 16 bytes: a wave-step's output -- (64 / T) whole rows, <= 2 KiB, contiguous in
+    // memory -- is assembled in this wave-private LDS image first (the pieces written at their byte offsets: unaligned LDS
+    // stores) and leaves as ALIGNED 16-byte stores; only the < 16 bytes in front of the first and behind the last aligned
+    // chunk go out as single bytes.  Unaligned 16-byte global stores (every piece of such a row) cost a quarter to a third of
+    // the kernel: 2.5e8 x 9 bit with hit counts, P = 63 / 64: 2.9 / 3.9 TB/s, 257 / 256: 3.5 / 4.5, 385 / 384: 2.9 / 4.0.
+    constexpr int STAGE_BYTES = RP == 1 ? 2048 + 64 : 16;
+    __shared__ __attribute__((aligned(16))) uint8_t ostage[kWavesPerBlock][STAGE_BYTES];
     __shared__ uint32_t s_hits[kMaxKeys];
     constexpr bool HIST = C <= 12; // hit counts by histogram of the values (see shared_wide2_kernel), else packed byte counters
     __shared__ uint32_t hist[HIST ? (1 << C) : 1];
@@ -1326,6 +1333,12 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
     const uint32_t rows_per_step = 64u / T;                         // whole rows a wave step covers; 64 mod T lanes idle
     const uint32_t last_bytes = RP == 1 ? P - 32 * (T - 1) : 32;    // bytes of a row's last piece, 1..32
     const bool aligned16 = (P & 15u) == 0;                          // every piece starts on a 16-byte boundary
+    // Where it pays: two lanes per row (P = 33 .. 63: a step's image is 32 rows, up to 2 KiB -- same box, with hit counts, P = 57 / 63:
+    // 2.81 / 2.86 -> 3.50 / 3.77 TB/s).  One lane per row loses (P = 9: 2.80 -> 1.88, P = 24: 3.93 -> 3.62: small images, the
+    // write -> wait -> read -> store chain per step is not hidden), and so do three and more (P = 65: 2.38 -> 2.02, 257: 3.15 -> 2.58:
+    // 64 mod T idle lanes, images of 1.3 KiB and more steps per tile).  (flags bit 14: never, for A/B)
+    // Single-table widths only: at c = 17 the image costs the kernel a resident block (P = 47: 2.62 -> 2.32 TB/s, 63: 2.96 -> 2.82).
+    const bool staged = RP == 1 && C <= 10 && !aligned16 && T == 2 && !(a.flags & 0x4000u);
     const bool use_hist = HIST && P >= 128;
 
     if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
@@ -1391,6 +1404,9 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
 #pragma unroll 1
         for (uint32_t s = 0; s < nsteps; s++) {
             const uint32_t row = row_first + s * row_step;
+            // the step's output: rows [s * row_step, ...) of the tile, contiguous bytes from step_g0 on
+            uint8_t *const step_g0 = out_tile + (uint64_t)(s * row_step) * P;
+            const uint32_t step_a0 = (uint32_t)((uintptr_t)step_g0 & 15u);
             if (row < rows_here && has_table) { // (rows beyond the column: nothing is written)
                 // the piece's RB bytes start at byte row * C of the tile: fetch the dwords around them, shift into place
                 const uint32_t byte0 = row * C;
@@ -1435,6 +1451,16 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
                     dst[0] = u32x4{y[0], y[1], y[2], y[3]};
                     // (the second row of the piece; it exists unless the column ends on the first)
                     if (row + 1 < rows_here) dst[1] = u32x4{y[4], y[5], y[6], y[7]};
+                } else if (staged) {
+                    // the piece at its byte offset inside the step's image (which starts at the step's global misalignment, so
+                    // that aligned chunks of the image are aligned chunks of memory)
+                    uint8_t *dst = ostage[wave] + step_a0 + (row - s * row_step) * P + 32u * quarter;
+                    if (piece_bytes == 32) {
+                        *(Unaligned16 *)dst = Unaligned16{y[0], y[1], y[2], y[3]};
+                        *(Unaligned16 *)(dst + 16) = Unaligned16{y[4], y[5], y[6], y[7]};
+                    } else {
+                        store_row_piece(dst, y, piece_bytes);
+                    }
                 } else {
                     uint8_t *dst = out_tile + (uint64_t)row * P + 32u * quarter;
                     if (piece_bytes == 32 && aligned16) {
@@ -1476,6 +1502,26 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
                 }
             }
             if (!use_hist && a.hits && ++since_flush == 31) flush_counts();
+            if (staged) {
+                const uint32_t first = s * row_step;
+                const uint32_t rows_in_step = first >= rows_here ? 0u : (rows_here - first < row_step ? rows_here - first : row_step);
+                const uint32_t nbytes = rows_in_step * P;
+                if (nbytes) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's image is complete (LDS is in order per wave)
+                    const uint8_t *img = ostage[wave];
+                    const uint32_t end = step_a0 + nbytes;                // image bytes [step_a0, end)
+                    const uint32_t c_lo = (step_a0 + 15u) / 16u, c_hi = end / 16u; // whole aligned chunks [c_lo, c_hi)
+                    uint8_t *const g_al = step_g0 - step_a0;              // 16-byte aligned
+                    for (uint32_t c = c_lo + (uint32_t)lane; c < c_hi; c += 64)
+                        *(u32x4 *)(g_al + 16u * c) = *(const u32x4 *)(img + 16u * c);
+                    // the bytes in front of the first and behind the last whole chunk (fewer than 16 each)
+                    const uint32_t head_end = c_lo * 16u < end ? c_lo * 16u : end;
+                    if (step_a0 + (uint32_t)lane < head_end) g_al[step_a0 + lane] = img[step_a0 + lane];
+                    const uint32_t tail0 = c_hi * 16u > head_end ? c_hi * 16u : head_end;
+                    if (tail0 + (uint32_t)lane < end) g_al[tail0 + lane] = img[tail0 + lane];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // image reads done before the next step overwrites it
+                }
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the tile's LDS reads are done: the next DMA may overwrite it
         const uint64_t next = tile + stride;

@@ -54,7 +54,8 @@ inline int scan_bpc(int occ_bpc, int tile_bytes, const LaunchReq &r)
 // static LDS of the multi-pass LUT kernel: four tiles, the per-block hit counters, ticket word and slack
 template <int C, int VPL> constexpr size_t lut_static_lds()
 {
-    return 4 * ScanGeom<C, VPL>::LDS_BYTES + kMaxKeys * 4 + 512 + (C <= 12 ? (size_t)(4u << C) : 16); // + the hit-count histogram
+    // + the hit-count histogram + shared_linear_kernel's output image (4 waves x 2112 bytes)
+    return 4 * ScanGeom<C, VPL>::LDS_BYTES + kMaxKeys * 4 + 512 + (C <= 12 ? (size_t)(4u << C) : 16) + 4 * 2112;
 }
 
 // the 32-keys-per-lookup kernel needs ceil(P/32) tables next to that in the CU's 160 KiB of LDS
@@ -296,13 +297,14 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 // bit 8: round 2's kernel, which gives the short table a whole lane per row, for A/B)
                 if (P == 16 && C > 10 && !(r.scan.flags & 16u))
                     hipLaunchKernelGGL((shared_linear_kernel<C, 2, 2>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);
-                // (2.5e8 x 9 bit, same box, TB/s with / without hit counts, shared_linear2_kernel against shared_linear_kernel:
-                // P = 33: 3.10 / 3.27 against 2.59 / 2.88, P = 40: 3.21 / 3.40 against 2.97 / 3.23, P = 48: 3.26 / 3.49 against
-                // 3.14 / 3.31, P = 63: 2.65 / 2.81 against 2.77 / 2.83; P = 12: 2.87 / 4.09 against 3.43 / 3.77; and the short
-                // table in steps of its own behind two or more full tables LOSES -- P = 100: 2.26 / 2.47 against 3.18 / 3.63,
-                // P = 300: 2.45 / 2.63 against 3.58 / 4.07: a step that writes 4 bytes of each of 64 rows is 64 partial-line
-                // transactions, where the old mapping's short lane sits in the same store instruction as its row's full pieces)
-                else if ((r.scan.flags & 256u) || !((P / 32 == 1 && P % 32 >= 1 && P % 32 <= 24) || (P < 32 && !r.scan.hits)))
+                // shared_linear2_kernel (the short last table on the full piece's lane / in steps of its own) is the product only for
+                // rows below 32 keys without hit counts (2.5e8 x 9 bit, same box: P = 12: 4.09 against 3.77 TB/s; with hit counts
+                // 2.87 against 3.43).  For rows of 33 .. 63 keys it beat round 2's kernel (P = 33: 3.10 against 2.59) until that kernel
+                // learnt to write such rows through an aligned LDS image (P = 47 / 52 / 56: 3.02 / 3.30 / 3.46 against 2.82 / 2.84 /
+                // 2.85; flags bit 15 brings it back for A/B), and its short-table steps LOSE behind two or more full tables -- P = 100:
+                // 2.26 against 3.18, P = 300: 2.45 against 3.58: a step that writes 4 bytes of each of 64 rows is 64 partial-line
+                // transactions, where the old mapping's short lane sits in the same store instruction as its row's full pieces.
+                else if ((r.scan.flags & 256u) || !(((r.scan.flags & 0x8000u) && P / 32 == 1 && P % 32 >= 1 && P % 32 <= 24) || (P < 32 && !r.scan.hits)))
                     hipLaunchKernelGGL((shared_linear_kernel<C, 2, 1>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);
                 else {
                     allow_dynamic_lds<shared_linear2_kernel<C, 2>>(max_dyn, r.device);
