@@ -328,6 +328,37 @@ def test_shared_scan_wide_and_many_keys(O, eng, c, P, layout):
     assert np.array_equal(hits.cpu().numpy().astype(np.uint64), ohits)
 
 
+@pytest.mark.parametrize("c", [5, 9, 10, 11, 16, 17, 20, 21, 25, 29, 30, 32])
+@pytest.mark.parametrize("count", [True, False])
+def test_shared_scan_round3_kernels(O, eng, c, count):
+    """the round-3 shared-scan kernels at the key counts and widths that select their variants: per-predicate one word at a
+    time (shared_wide3_kernel: hit counts in registers for one round / two packed rounds / none; byte digits and the wider
+    digits of c = 17 .. 20, 25 .. 30), linear rows through the LDS stage (32 .. 40 keys), through the aligned output image
+    (41 .. 63 keys, c <= 10) and with the short table on the full piece's lane (below 32 keys without hit counts) -- several
+    tiles, a ragged tail, duplicate and out-of-range keys"""
+    n = 3 * 4096 + 2048 + 77
+    vals, col = make_column(O, eng, n, c, 4200 + c)
+    packed_host = col.data.cpu().numpy()
+    nb = (n + 7) // 8
+    for layout, counts in (("per_predicate", (9, 16, 31, 32, 33, 48, 63, 64, 65)), ("linear", (12, 24, 32, 36, 40, 41, 47, 52, 63, 64))):
+        for P in counts:
+            rng = np.random.default_rng(c * 977 + P)
+            keys = [int(vals[int(i)]) for i in rng.integers(0, n, size=P)]
+            keys[1] = keys[0]                      # duplicate key
+            if c < 31:
+                keys[2] = (1 << c) + 5             # out of range: matches nothing
+            keys[3] = -1
+            keys = [k if k < 2 ** 31 else k - 2 ** 32 for k in keys]
+            out, hits = eng.shared_scan(keys, col, layout=layout, hits=None if count else False)
+            oout, ohits = O.shared_scan_eq(packed_host, n, c, keys, layout)
+            got = out.cpu().numpy()
+            if layout == "per_predicate":
+                got = got[:, :nb]
+            assert np.array_equal(got, oout), (layout, P, c)
+            if count:
+                assert np.array_equal(hits.cpu().numpy().astype(np.uint64), ohits), (layout, P, c)
+
+
 @pytest.mark.parametrize("c,P", [(32, 1024), (25, 900), (31, 705)])
 @pytest.mark.parametrize("layout", ["per_predicate", "linear"])
 @pytest.mark.parametrize("count", [True, False])
