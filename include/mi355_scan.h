@@ -90,8 +90,7 @@ MI355_API int mi355_ctx_set_stream(mi355_ctx *ctx, void *hip_stream);
  * the HBM->LDS loads, 0 default / 2 non-temporal; bit 4: non-temporal output stores in decompress; default 18),
  * "scan_nt_stores" (result stores of the scans: -1 chosen by output size (default: write-through while the bitmap fits
  * the Infinity Cache, non-temporal beyond), 0 plain, 1 non-temporal, 2 write-through), "select_kernel" (mi355_scan_select_dev:
- * 0 = chosen by the fraction of the value range the predicate accepts (default), 1 = the single-role kernel, 2 = decoder /
- * expander roles), "kernel_flags" (A/B switches of the kernels; results never depend on them except the two timing
+ * 0 / 2 = decoder / expander roles (default), 1 = the older single-role kernel, kept for A/B runs), "kernel_flags" (A/B switches of the kernels; results never depend on them except the two timing
  * ablations of the selection documented in DESIGN.md) */
 MI355_API int mi355_ctx_set_option(mi355_ctx *ctx, const char *name, int value);
 

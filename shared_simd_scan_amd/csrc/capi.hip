@@ -714,19 +714,11 @@ int mi355_scan_select_dev(mi355_ctx *ctx, const void *packed_dev, uint64_t n, un
     r.scan.capacity = capacity;
     r.scan.first_row = first_row;
     fill_predicate(r.scan, c, op, a, b);
-    // Which kernel: select_kernel (one wave does everything in turn) is 8 % ahead when few rows qualify, select2_kernel
-    // (decoder + expander waves) 1.2 - 2.5 x ahead when many do (1e9 x 9 bit: 0.28 against 0.30 ms at 1/512; 0.39 / 1.20 / 1.47
-    // against 0.32 / 0.47 / 1.07 ms at 1/64, 1/8, 1/2).  The count is not known before the launch: go by the fraction of the value
-    // range the predicate accepts (what it selects of uniformly distributed values) -- at most 1/128: the single-role kernel.
-    // A wrong guess costs time, never the result.  Option "select_kernel": 0 this rule, 1 / 2 force.
-    {
-        const double range = c >= 32 ? 4294967296.0 : (double)(1ull << c);
-        double frac = ((double)r.scan.key[1] + 1.0) / range; // accepted span (fill_predicate: key[1] = hi - lo)
-        if (r.scan.key[0] == 0xffffffffu && r.scan.key[1] == 0 && c < 32) frac = 0.0; // the empty predicate
-        if (r.scan.invert) frac = 1.0 - frac;
-        if (mask_dev && mask_op != MI355_BITMAP_AND && mask_op != MI355_BITMAP_ANDNOT) frac = 1.0; // OR / XOR with an unknown bitmap
-        r.select_single = ctx->select_kernel == 1 || (ctx->select_kernel == 0 && frac <= 1.0 / 128.0);
-    }
+    // Which kernel: select2_kernel (decoder + expander waves, one look-back per block and generation) is ahead of the
+    // single-role select_kernel at every width and selectivity measured (profiles/r03_select_widths.txt: 1.01 - 1.2 x when
+    // almost nothing qualifies, 1.2 - 3.3 x from 1/64 up), so it is what runs; option "select_kernel" = 1 keeps the older kernel
+    // reachable for A/B runs (0 / 2: select2_kernel).
+    r.select_single = ctx->select_kernel == 1;
     return launch(ctx, r);
 }
 

@@ -20,7 +20,7 @@ struct LaunchReq {
     int dma_aux;           // cache policy of the HBM->LDS loads: 0 default, 2 nt
     int scan_nt_stores;    // bitmap stores of the eq / range scan: -1 by size, 0 plain, 1 non-temporal
     int scan_burst;        // eq / range scan: 0 = tiles per store burst chosen by width (burst_k), 1 = one tile per burst
-    int select_single;     // kOpSelect: 1 = the single-role kernel (select_kernel: best for selective predicates), 0 = decoder / expander roles
+    int select_single;     // kOpSelect: 1 = the older single-role kernel (option "select_kernel" = 1, A/B), 0 = decoder / expander roles
     int shared_vpl;        // shared scans of <= 8 keys: values per lane and tile, 0 = the engine's choice, 64, 128 (c <= 12)
     int *choice_out;       // kOpSharedScan: non-null = only report the kernel family that would run (0 one-pass LUT,
                            // 1 byte-entry multi-pass LUT, 2 dword-entry LUT, 3 compare chain), launch nothing

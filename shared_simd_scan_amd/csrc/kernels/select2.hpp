@@ -15,9 +15,9 @@ namespace mi355 {
 // at 1/2 -- where the unfused chain's expansion kernel, eight waves per SIMD, needs 1.0 ms for everything.
 //
 // Here a block is TWELVE waves on the same LDS: waves 0-3 DECODE (one per SIMD: chunk -> bitmap words parked in LDS,
-// chunk count published), waves 4-11 EXPAND (two per SIMD) the chunks the decoders parked one generation earlier: the
-// first expander of a chunk does the decoupled look-back and hands the chunk's base to the other through LDS, and
-// the chunk's tiles are dealt out to the two (sixteen waves -- 128 VGPRs each -- made the decode spill: 0.33 ms against 0.19).  A block barrier per generation is the whole producer / consumer
+// chunk count added to the block's), waves 4-11 EXPAND (two per SIMD) the chunks the decoders parked one generation earlier:
+// wave 4 does the block's decoupled look-back and hands every chunk's base to its expanders through LDS, and
+// a chunk's tiles are dealt out to its two (sixteen waves -- 128 VGPRs each -- made the decode spill: 0.33 ms against 0.19).  A block barrier per generation is the whole producer / consumer
 // protocol (generation g: decoders fill buffer g & 1, expanders drain buffer (g - 1) & 1).  The look-back and the
 // expansion no longer cost the decoders anything, and the expansion's instruction streams run four to a SIMD.
 //
@@ -31,7 +31,8 @@ namespace mi355 {
 // poison-on-give-up and the atomic-max count are select_kernel's.
 constexpr int kSel2Waves = 12;
 constexpr int kSel2Decoders = 4;
-constexpr int kSel2ExpPerDec = (kSel2Waves - kSel2Decoders) / kSel2Decoders; // 3
+constexpr int kSel2ExpPerDec = (kSel2Waves - kSel2Decoders) / kSel2Decoders; // 2
+constexpr int kSel2Window = 4; // state words per lane and poll of the block's look-back (256 super-chunks per poll)
 // ids per tile up to which a tile goes through the expander's LDS stage: 2048, or 1024 where the CU's 160 KiB leave no more
 // next to the tiles, the parked chunks and the narrow widths' predicate table (12 expanders x 2 bytes x this)
 constexpr int sel2_stage_ids(int fixed_lds_bytes)
@@ -57,6 +58,8 @@ __global__ __launch_bounds__(kSel2Waves * 64, 1) void select2_kernel(ScanArgs a)
     __shared__ unsigned long long s_chunk[D][2];        // chunk parked in the buffer (~0: none)
     __shared__ unsigned long long s_hits[D][2];         // its hit count
     __shared__ int s_ntiles[D][2];                      // its tiles inside the column
+    __shared__ unsigned long long s_sum[2];             // the generation's ids over the block's D chunks (LDS atomic adds)
+    __shared__ unsigned int s_arrive[2];                // decoders that have added theirs
     __shared__ unsigned long long s_base[D];            // look-back result: ids in front of the chunk being expanded
     __shared__ unsigned int s_base_tag[D];              // generation + 1 the base belongs to; bit 31: the look-back gave up
     __shared__ uint32_t s_tilepre[D][K];                // ids of the chunk being expanded in front of each of its tiles
@@ -105,6 +108,10 @@ __global__ __launch_bounds__(kSel2Waves * 64, 1) void select2_kernel(ScanArgs a)
         mail[1] = __hip_atomic_fetch_add(ticket, (unsigned long long)D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x < D) s_base_tag[threadIdx.x] = s_pre_tag[threadIdx.x] = 0;
+    if (threadIdx.x < 2) {
+        s_sum[threadIdx.x] = 0;
+        s_arrive[threadIdx.x] = 0;
+    }
     if constexpr (LK > 0) {
         constexpr uint32_t fmask = (1u << C) - 1u;
         for (uint32_t en = threadIdx.x; en < (1u << (LK * C)); en += kSel2Waves * 64) {
@@ -131,15 +138,23 @@ __global__ __launch_bounds__(kSel2Waves * 64, 1) void select2_kernel(ScanArgs a)
         __builtin_amdgcn_s_setprio(0);
     bool gave_up = false;
     uint32_t dbg_polls = 0, dbg_retries = 0, dbg_tagspins = 0; // (flags bit 6: diagnostics, written behind the count)
-    // ---- the look-back (select.hpp: one poll = kSelectWindow loads of 64 consecutive state words) ----------------------
-    auto poll_issue = [&](int64_t pos, unsigned long long (&s)[kSelectWindow]) {
+    // ---- the look-back, one per BLOCK and generation -------------------------------------------------------------------
+    // A block's D chunks of a generation are consecutive (one ticket), so the look-back's unit is the block-generation
+    // ("super-chunk" base / D): its aggregate leaves with the last of the block's decoders to finish (LDS atomics below), ONE
+    // expander wave (wave D) looks back over the super-chunks in front and hands every decoder's chunk its base through
+    // LDS.  One poll = W loads of 64 consecutive state words = 256 super-chunks, the whole grid's generation.  (Round 3's
+    // first form looked back per chunk: four waves per block polling 1024 state words = 8 KiB each, two or three times per
+    // generation -- a quarter of the column's own traffic through the same L2 and address pipelines, and 0.08 ms on a
+    // 0.21 ms decode.)
+    constexpr int W = kSel2Window;
+    auto poll_issue = [&](int64_t pos, unsigned long long (&s)[W]) {
 #pragma unroll
-        for (int k = 0; k < kSelectWindow; k++) {
+        for (int k = 0; k < W; k++) {
             const int64_t i = pos - 64 * k - lane;
             s[k] = i >= 0 ? __hip_atomic_load(state + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
         }
     };
-    auto resolve = [&](uint64_t q, unsigned long long q_hits, unsigned long long (&s)[kSelectWindow]) -> unsigned long long {
+    auto resolve = [&](uint64_t q, unsigned long long q_hits, unsigned long long (&s)[W]) -> unsigned long long {
         if (q == 0) return 0ull; // chunk 0 published its inclusive prefix right away
         unsigned long long before = 0;
         int64_t pos = (int64_t)q - 1;
@@ -150,7 +165,7 @@ __global__ __launch_bounds__(kSel2Waves * 64, 1) void select2_kernel(ScanArgs a)
             unsigned long long prefix = 0;
             bool retry = false;
 #pragma unroll
-            for (int k = 0; k < kSelectWindow; k++) {
+            for (int k = 0; k < W; k++) {
                 if (!done && !retry) { // wave-uniform
                     const uint32_t status = (uint32_t)(s[k] >> 62);
                     const unsigned long long fmask = __ballot(status == 2);
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(kSel2Waves * 64, 1) void select2_kernel(ScanArgs a)
                 }
                 __builtin_amdgcn_s_sleep(32); // (a decoder shares this SIMD: poll rarely)
             } else if (!done) {
-                pos -= 64 * kSelectWindow;
+                pos -= 64 * W;
             }
             if (!done) poll_issue(pos, s);
         }
@@ -387,40 +402,73 @@ __global__ __launch_bounds__(kSel2Waves * 64, 1) void select2_kernel(ScanArgs a)
                 }
             }
             unsigned long long chunk_hits = 0;
-            if (have) {
-                // the chunk's hits, published as its aggregate (chunk 0: as the first inclusive prefix)
-                chunk_hits = wave_sum(lane_hits);
-                if (lane == 0)
-                    __hip_atomic_store(state + chunk, ((chunk == 0 ? 2ull : 1ull) << 62) | chunk_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (have) chunk_hits = wave_sum(lane_hits);
             if (wave == 0) stamp(1);
             if (lane == 0) {
                 s_chunk[d][buf] = have ? chunk : ~0ull;
                 s_hits[d][buf] = chunk_hits;
                 s_ntiles[d][buf] = ntiles_here;
                 if (claiming) mail[buf] = pending_ticket;
+                if (dec_active) {
+                    // the super-chunk's aggregate (super-chunk 0: the first inclusive prefix) leaves with the last decoder
+                    __hip_atomic_fetch_add(&s_sum[buf], chunk_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (__hip_atomic_fetch_add(&s_arrive[buf], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)(D - 1)) {
+                        const unsigned long long total = __hip_atomic_load(&s_sum[buf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint64_t sc = base / D;
+                        __hip_atomic_store(state + sc, ((sc == 0 ? 2ull : 1ull) << 62) | (total & kSelectValueMask), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
         } else if (exp_active) {
             // ---- expand the chunk decoder d parked in the generation before ------------------------------------------------------
             const int pb = buf ^ 1;
+            const bool look_back = !(a.flags & 4u); // (flags: timing ablations)
+            const bool looker = wave == D;          // first expander of decoder 0: the block's look-back
+            unsigned long long before = 0;
+            if (looker) {
+                const uint64_t sc = prev_base / D;
+                unsigned long long s[W];
+                // (tried: 7 us of sleep in front of the first poll, so that the slower blocks of the generation that has just
+                // ended have published -- fewer repeats, the same time)
+                if (look_back && sc > 0) poll_issue((int64_t)sc - 1, s);
+                const unsigned long long total = uniform64(s_sum[pb]);
+                unsigned long long hd[D];
+#pragma unroll
+                for (int j = 0; j < D; j++) hd[j] = uniform64(s_hits[j][pb]);
+                if (lane == 0) { // (the decoders add to these again in the generation after this one, behind the barrier)
+                    s_sum[pb] = 0;
+                    s_arrive[pb] = 0;
+                }
+                stamp(2);
+                if (look_back) before = resolve(sc, total, s);
+                stamp(3);
+                if (lane == 0) {
+                    unsigned long long run = before;
+#pragma unroll
+                    for (int j = 0; j < D; j++) {
+                        s_base[j] = run; // (release: the base is in LDS before its tag)
+                        run += hd[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < D; j++)
+                        __hip_atomic_store(&s_base_tag[j], (gen + 1u) | (gave_up ? 0x80000000u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // the column's hit count: atomic max over a word the entry point zeroed, so a give-up's ~0 always wins
+                    if (prev_base + D >= nchunks && !gave_up)
+                        __hip_atomic_fetch_max(a.hits, before + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             const uint64_t q = uniform64(s_chunk[d][pb]);
             if (q != ~0ull) {
                 const unsigned long long q_hits = uniform64(s_hits[d][pb]);
                 const int ntiles_q = __builtin_amdgcn_readfirstlane(s_ntiles[d][pb]);
                 uint32_t(*const pk)[64 * WORDS] = parked[d][pb];
-                const bool look_back = !(a.flags & 4u), want_ids = q_hits && !(a.flags & 2u); // (flags: timing ablations)
-                unsigned long long before = 0;
-                unsigned long long s[kSelectWindow];
-                if (e == 0 && look_back && q > 0) {
-                    // (tried: 7 us of sleep in front of the first poll, so that the slower blocks of the generation that has just
-                    // ended have published -- fewer repeats, the same time)
-                    poll_issue((int64_t)q - 1, s);
-                }
-                // a sparse chunk (the usual case of a selective predicate) is the first expander's alone: no tile prefixes, no
-                // hand-over, the other expanders leave the SIMD to the decoder
+                const bool want_ids = q_hits && !(a.flags & 2u);
+                // a sparse chunk (the usual case of a selective predicate) is its first expander's alone: no tile prefixes, no
+                // hand-over, the other expander leaves the SIMD to the decoder
                 const bool sparse_chunk = q_hits <= 64ull * K;
                 if (want_ids && !sparse_chunk && e == kSel2ExpPerDec - 1) {
-                    // pass 1, by the chunk's LAST expander while the first one looks back: every tile's id count -> exclusive
+                    // pass 1, by the chunk's LAST expander while the block's look-back runs: every tile's id count -> exclusive
                     // prefix inside the chunk, for all of the chunk's expanders (two tiles per DPP scan, 16-bit fields: a tile
                     // has at most 8192 ids; the scans are independent chains)
                     uint32_t tot[K];
@@ -447,17 +495,17 @@ __global__ __launch_bounds__(kSel2Waves * 64, 1) void select2_kernel(ScanArgs a)
                         __hip_atomic_store(&s_pre_tag[d], gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
-                if (e == 0) {
-                    if (wave == D) stamp(2);
-                    if (look_back) before = resolve(q, q_hits, s);
-                    if (wave == D) stamp(3);
-                    if (lane == 0) {
-                        s_base[d] = before; // (release: the base is in LDS before its tag)
-                        __hip_atomic_store(&s_base_tag[d], (gen + 1u) | (gave_up ? 0x80000000u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    // the column's hit count: atomic max over a word the entry point zeroed, so a give-up's ~0 always wins
-                    if (q == nchunks - 1 && lane == 0 && !gave_up)
-                        __hip_atomic_fetch_max(a.hits, before + q_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (want_ids && !looker && (sparse_chunk ? e == 0 : true)) { // the chunk's base from the block's look-back
+                    unsigned int tag;
+                    uint32_t spins = 0;
+                    do {
+                        tag = __hip_atomic_load(&s_base_tag[d], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if ((tag & 0x7fffffffu) == gen + 1u) break;
+                        dbg_tagspins++;
+                        __builtin_amdgcn_s_sleep(16); // (a decoder shares this SIMD: poll rarely)
+                    } while (++spins < (1u << 28));
+                    gave_up = gave_up || (tag & 0x80000000u) || (tag & 0x7fffffffu) != gen + 1u;
+                    before = uniform64(__hip_atomic_load(&s_base[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 }
                 if (want_ids && sparse_chunk) {
                     if (e == 0 && !gave_up) {
@@ -481,18 +529,6 @@ __global__ __launch_bounds__(kSel2Waves * 64, 1) void select2_kernel(ScanArgs a)
                         uint32_t spins = 0;
                         while (__hip_atomic_load(&s_pre_tag[d], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != gen + 1u && ++spins < (1u << 28))
                             __builtin_amdgcn_s_sleep(16);
-                    }
-                    if (e != 0) { // wait for the chunk's base from expander 0
-                        unsigned int tag;
-                        uint32_t spins = 0;
-                        do {
-                            tag = __hip_atomic_load(&s_base_tag[d], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if ((tag & 0x7fffffffu) == gen + 1u) break;
-                            dbg_tagspins++;
-                            __builtin_amdgcn_s_sleep(64); // (a decoder shares this SIMD: poll rarely)
-                        } while (++spins < (1u << 28));
-                        gave_up = gave_up || (tag & 0x80000000u) || (tag & 0x7fffffffu) != gen + 1u;
-                        before = uniform64(__hip_atomic_load(&s_base[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                     }
                     if (!gave_up) {
                         // pass 2: this expander's tiles (k = e, e + kSel2ExpPerDec, ...), ONE instance of the expansion code

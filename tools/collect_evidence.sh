@@ -12,6 +12,7 @@ grep -v amdgpu.ids $O/bench_next.txt > profiles/${TAG}_next_rows_1e9x9.txt
 grep -v amdgpu.ids $O/pcie.txt > profiles/${TAG}_host_pointer_pcie.txt
 grep -v amdgpu.ids $O/shard_sizes.txt > profiles/${TAG}_shard_sizes_1gpu.txt
 grep -v amdgpu.ids $O/select_ab.txt > profiles/${TAG}_select_ab.txt
+grep -v amdgpu.ids $O/select_widths.txt > profiles/${TAG}_select_widths.txt
 cp $O/wide_widths.txt profiles/${TAG}_wide_widths_after.txt
 cp $O/bench.json profiles/${TAG}_bench_line.json
 cp $O/bench_random.json profiles/${TAG}_bench_line_random_column.json

@@ -18,6 +18,7 @@ python tools/bench_next.py > $O/bench_next.txt 2>&1; echo "bench_next rc=$?"
 python tools/pcie_rate.py > $O/pcie.txt 2>&1; echo "pcie rc=$?"
 python tools/shard_sizes.py > $O/shard_sizes.txt 2>&1; echo "shard sizes rc=$?"
 python tools/select_ablate.py > $O/select_ab.txt 2>&1; echo "select ablate rc=$?"
+python tools/select_widths.py > $O/select_widths.txt 2>&1; echo "select widths rc=$?"
 python tools/profile_shared.py --bits 17,21,25 --P 16,64 --out $O/wide_widths.txt > /dev/null 2>&1; echo "wide widths profile rc=$?"
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 python bench.py --column random > $O/bench_random.json 2>> $O/bench.err; echo "bench random rc=$?"

@@ -15,7 +15,8 @@ eng = ScanEngine(0)
 n, c = 1_000_000_000, 9
 col = eng.generate("splitmix", n, c, 42)
 eng.set_option("kernel_flags", 16384)
-for op, x, cap in ((0, 77, 4_000_000), (2, 64, 130_000_000)):  # MI355_CMP_EQ, MI355_CMP_LT
+eng.set_option("select_kernel", 2)
+for op, x, cap in ((0, 77, 4_000_000), (2, 8, 20_000_000), (2, 64, 130_000_000), (2, 256, 510_000_000)):  # MI355_CMP_EQ, MI355_CMP_LT
     ids = torch.zeros(cap + 1024, dtype=torch.int64, device="cuda")
     for rep in range(3):
         cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
