@@ -1426,9 +1426,11 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
                 for (int h = 0; h < RP; h++) {
                     uint32_t m[8];
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        m[i] = L::lookup(table, x[8 * h + i]);
-                        if ((uint32_t)(8 * h + i) >= nvalid) m[i] = 0u;
+                    for (int i = 0; i < 8; i++) m[i] = L::lookup(table, x[8 * h + i]);
+                    if (vals_here != (uint32_t)G::TILE_VALUES) { // wave-uniform: only the column's last tile can hold a short row
+#pragma unroll
+                        for (int i = 0; i < 8; i++)
+                            if ((uint32_t)(8 * h + i) >= nvalid) m[i] = 0u;
                     }
                     const uint32_t r0[4] = {m[0], m[1], m[2], m[3]}, r1[4] = {m[4], m[5], m[6], m[7]};
                     uint32_t lo4[4], hi4[4];
@@ -1586,8 +1588,10 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear2_kernel(ScanArgs 
     const uint32_t P = a.nkeys;
     const uint32_t Tf = P / 32, R = P % 32;                        // full tables; keys of the short last one
     const uint32_t T = Tf + (R ? 1u : 0u);
-    const bool attached = Tf == 1 && R != 0;                       // the short piece rides on the full piece's lane
-    const bool dedicated = R != 0 && Tf != 1;                      // ... or gets steps of its own
+    // the short piece rides on the lane of the row's LAST full piece (Tf = 1; behind two to five full tables when it is short
+    // enough for the launcher to ask for it: flags bit 17) ...
+    const bool attached = R != 0 && (Tf == 1 || (Tf >= 2 && (a.flags & 0x20000u)));
+    const bool dedicated = R != 0 && !attached;                    // ... or gets steps of its own
     const bool aligned16 = (P & 15u) == 0;                         // every full piece starts on a 16-byte boundary
     const bool use_hist = HIST && P >= 128;
 
@@ -1657,12 +1661,15 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear2_kernel(ScanArgs 
     };
     // one piece: 8 lookups in `table`, regroup to key-bytes, 8x8 bit transposes of the key-bytes in use, store, count.
     // nbytes (1 .. 32) is wave-uniform.
+    bool ragged_tile = false;
     auto piece = [&](const uint32_t (&x)[8], const uint32_t *table, uint32_t nbytes, uint32_t nvalid, uint8_t *dst, uint32_t (&cb)[8]) {
         uint32_t m[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            m[i] = L::lookup(table, x[i]);
-            if ((uint32_t)i >= nvalid) m[i] = 0u;
+        for (int i = 0; i < 8; i++) m[i] = L::lookup(table, x[i]);
+        if (ragged_tile) { // wave-uniform: only the column's last tile can hold a short row
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if ((uint32_t)i >= nvalid) m[i] = 0u;
         }
         uint32_t y[8];
         if (nbytes <= 8u) { // one key-byte: gather the low bytes of the 8 dwords
@@ -1719,6 +1726,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear2_kernel(ScanArgs 
         const uint64_t left = tc.n - tile * G::TILE_VALUES;
         const uint32_t vals_here = left >= (uint64_t)G::TILE_VALUES ? (uint32_t)G::TILE_VALUES : (uint32_t)left;
         const uint32_t rows_here = (vals_here + 7) / 8;
+        ragged_tile = vals_here != (uint32_t)G::TILE_VALUES;
         uint8_t *const out_tile = a.out + tile * (uint64_t)ROWS * P;
         // one step of short pieces: rows [64 j, 64 j + 64), a lane per row
         auto short_step = [&](uint32_t j) {
@@ -1740,7 +1748,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear2_kernel(ScanArgs 
                 fetch(row, x);
                 const uint32_t nvalid = vals_here - row * 8 >= 8u ? 8u : vals_here - row * 8; // short only at the column's end
                 piece(x, table_full, 32u, nvalid, out_tile + (uint64_t)row * P + 32u * quarter, cbf);
-                if (attached) piece(x, table_short, R, nvalid, out_tile + (uint64_t)row * P + 32u, cbs);
+                if (attached && quarter + 1 == Tq) piece(x, table_short, R, nvalid, out_tile + (uint64_t)row * P + 32u * Tf, cbs);
                 if (HIST && use_hist && a.hits) {
                     // (Tf >= 8: one value per lane, picked by a select chain -- one atomic instruction per step)
                     if (Tf >= 8) {
@@ -1759,7 +1767,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear2_kernel(ScanArgs 
             }
             if (count_packed) {
                 if (++since_f == 31) flush(cbf, 32u * quarter, since_f);
-                if (attached && ++since_s == 31) flush(cbs, 32u, since_s);
+                if (attached && ++since_s == 31) flush(cbs, 32u * Tf, since_s);
             }
             if (dedicated) { // short pieces of the 64-row blocks the full steps have passed
                 const uint32_t covered = (s + 1) * rows_per_step;

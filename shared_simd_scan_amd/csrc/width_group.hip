@@ -154,6 +154,25 @@ inline bool shared_lut_prefers_vpl128(int c, uint32_t P, bool linear)
     return !linear && P <= 4;
 }
 
+// linear rows: does the short last table (R = P mod 32 keys behind Tf = P / 32 full ones) ride on the lane of the row's last full
+// piece (shared_linear2_kernel's attached mode) instead of getting a lane of its own (shared_linear_kernel)?  Attached, a
+// wave-step covers 64 / Tf rows instead of 64 / (Tf + 1) and pays the short piece's instructions with 1 / Tf of the lanes in
+// use.  Measured at every Tf = 2 .. 8, 12, 15 and R = 1 .. 31 (2.5e8 x 9 bit, profiles/r03_linear_attach_ab.txt): where the row
+// gain is >= 1.19 x it wins at (almost) every R -- 1.0 - 1.4 x; where it is 1.10 .. 1.18 x only for R <= 8; where the row
+// count does not change (Tf = 11, 13 .. 15, ...) it loses 10 - 20 %.  (flags bit 16: never, bit 18: always, for A/B)
+static inline bool attach_short(unsigned P, unsigned flags, bool hits)
+{
+    const unsigned Tf = P / 32, R = P % 32;
+    if (Tf < 2 || R == 0) return false;
+    if (flags & 0x40000u) return true;
+    if (flags & 0x10000u) return false;
+    const unsigned rows_attached = 64 / Tf, rows_own_lane = 64 / (Tf + 1);
+    if (rows_attached * 100 >= rows_own_lane * 119) return !(Tf == 3 && R > 24);
+    // (Tf = 7 with hit counts: the old mapping's eight lanes per row count one value each with a single LDS atomic)
+    if (rows_attached * 100 >= rows_own_lane * 110) return R <= 8 && !(Tf == 7 && hits);
+    return false;
+}
+
 template <int C> hipError_t launch_width(const LaunchReq &r)
 {
     switch (r.op) {
@@ -304,11 +323,15 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 // 2.85; flags bit 15 brings it back for A/B), and its short-table steps LOSE behind two or more full tables -- P = 100:
                 // 2.26 against 3.18, P = 300: 2.45 against 3.58: a step that writes 4 bytes of each of 64 rows is 64 partial-line
                 // transactions, where the old mapping's short lane sits in the same store instruction as its row's full pieces.
-                else if ((r.scan.flags & 256u) || !(((r.scan.flags & 0x8000u) && P / 32 == 1 && P % 32 >= 1 && P % 32 <= 24) || (P < 32 && !r.scan.hits)))
+                // Rows of 65 and more keys with a short last table: attach_short() above decides between the two mappings.
+                else if ((r.scan.flags & 256u) ||
+                         !(((r.scan.flags & 0x8000u) && P / 32 == 1 && P % 32 >= 1 && P % 32 <= 24) || (P < 32 && !r.scan.hits) || attach_short(P, r.scan.flags, r.scan.hits != nullptr)))
                     hipLaunchKernelGGL((shared_linear_kernel<C, 2, 1>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);
                 else {
+                    ScanArgs a2 = r.scan;
+                    if (attach_short(P, r.scan.flags, r.scan.hits != nullptr)) a2.flags |= 0x20000u;
                     allow_dynamic_lds<shared_linear2_kernel<C, 2>>(max_dyn, r.device);
-                    hipLaunchKernelGGL((shared_linear2_kernel<C, 2>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+                    hipLaunchKernelGGL((shared_linear2_kernel<C, 2>), lgrid, dim3(kBlockThreads), dyn, r.stream, a2);
                 }
             } else if (!linear && !(r.scan.flags & 2u)) { // (flags bit 1: the per-group kernel, for A/B)
                 // Hit counts in registers (flags bit 3: per-tile wave reductions / the histogram instead, for A/B): one 32-key

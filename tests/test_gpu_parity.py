@@ -334,13 +334,14 @@ def test_shared_scan_round3_kernels(O, eng, c, count):
     """the round-3 shared-scan kernels at the key counts and widths that select their variants: per-predicate one word at a
     time (shared_wide3_kernel: hit counts in registers for one round / two packed rounds / none; byte digits and the wider
     digits of c = 17 .. 20, 25 .. 30), linear rows through the LDS stage (32 .. 40 keys), through the aligned output image
-    (41 .. 63 keys, c <= 10) and with the short table on the full piece's lane (below 32 keys without hit counts) -- several
-    tiles, a ragged tail, duplicate and out-of-range keys"""
+    (41 .. 63 keys, c <= 10), with the short last table in steps of its own (below 32 keys without hit counts) and on the lane
+    of the row's last full piece (65 keys and more, where launch_width's attach_short() says so) -- several tiles, a ragged
+    tail, duplicate and out-of-range keys"""
     n = 3 * 4096 + 2048 + 77
     vals, col = make_column(O, eng, n, c, 4200 + c)
     packed_host = col.data.cpu().numpy()
     nb = (n + 7) // 8
-    for layout, counts in (("per_predicate", (9, 16, 31, 32, 33, 48, 63, 64, 65)), ("linear", (12, 24, 32, 36, 40, 41, 47, 52, 63, 64))):
+    for layout, counts in (("per_predicate", (9, 16, 31, 32, 33, 48, 63, 64, 65)), ("linear", (12, 24, 32, 36, 40, 41, 47, 52, 63, 64, 65, 80, 95, 97, 129, 159, 200, 225, 300, 513))):
         for P in counts:
             rng = np.random.default_rng(c * 977 + P)
             keys = [int(vals[int(i)]) for i in rng.integers(0, n, size=P)]

@@ -20,5 +20,7 @@ python tools/shard_sizes.py > $O/shard_sizes.txt 2>&1; echo "shard sizes rc=$?"
 python tools/select_ablate.py > $O/select_ab.txt 2>&1; echo "select ablate rc=$?"
 python tools/select_widths.py > $O/select_widths.txt 2>&1; echo "select widths rc=$?"
 python tools/profile_shared.py --bits 17,21,25 --P 16,64 --out $O/wide_widths.txt > /dev/null 2>&1; echo "wide widths profile rc=$?"
+# the bench line's roofline.traffic comes from THIS run's PMC passes: summarise them into the box's profiles/ first
+for w in scan_eq scan_range shared_scan decompress; do python tools/summarize_profile.py gpurun_out/prof_${TAG}_$w $w $TAG 1000000000 9 > /dev/null 2>&1; done
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 python bench.py --column random > $O/bench_random.json 2>> $O/bench.err; echo "bench random rc=$?"
