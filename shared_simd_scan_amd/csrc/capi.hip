@@ -130,7 +130,7 @@ int launch(mi355_ctx *ctx, LaunchReq &r)
     // option and arrive as its bits 1-4: two TIMING ablations (2 no expansion, 4 no look-back: wrong ids by construction) and
     // two A/B switches of the chunk hand-out (8 chunks dealt out by block index as in round 2, 16 no barrier per generation)
     // (option bits 13.. = further switches of the shared scans; they arrive as their bits 9..)
-    r.scan.flags = r.op == kOpSelect ? ((ctx->kernel_flags >> 8) & 0x7eu) : ((ctx->kernel_flags & 0x1ffu) | ((ctx->kernel_flags >> 4) & 0x5fe00u));
+    r.scan.flags = r.op == kOpSelect ? ((ctx->kernel_flags >> 8) & 0x7eu) : ((ctx->kernel_flags & 0x1ffu) | ((ctx->kernel_flags >> 4) & 0xdfe00u));
     r.scan.scratch = ctx->kernel_scratch;
     if (r.max_blocks_per_cu == 0 && !ctx->tuned_bpc.empty()) {
         const bool scan = r.op == kOpScanEq || r.op == kOpScanRange;

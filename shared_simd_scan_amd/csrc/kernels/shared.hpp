@@ -1338,7 +1338,41 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
     // write -> wait -> read -> store chain per step is not hidden), and so do three and more (P = 65: 2.38 -> 2.02, 257: 3.15 -> 2.58:
     // 64 mod T idle lanes, images of 1.3 KiB and more steps per tile).  (flags bit 14: never, for A/B)
     // Single-table widths only: at c = 17 the image costs the kernel a resident block (P = 47: 2.62 -> 2.32 TB/s, 63: 2.96 -> 2.82).
-    const bool staged = RP == 1 && C <= 10 && !aligned16 && T == 2 && !(a.flags & 0x4000u);
+    // Copying the image out a step late (below) left every one of these figures where it was -- with it and flags bit 19 (the image at
+    // every T) P = 9 / 17 with hit counts run at 0.67 / 0.72 x, P = 300 / 511 at 0.75 / 0.70 x of the direct stores: the image's LDS
+    // traffic (unaligned ds_write_b128 + the read back), not a wait, is what it costs.
+    const bool staged = RP == 1 && C <= 10 && !aligned16 && !(a.flags & 0x4000u) && (T == 2 || (a.flags & 0x80000u));
+    // The image of step s leaves during step s + 1: its LDS reads are issued in front of that step's decode (a wave's LDS
+    // operations execute in order, so they see step s's pieces and are not disturbed by step s + 1's, which follow them),
+    // its global stores behind it -- the read latency passes behind the lookups and transposes instead of in front of the stores.
+    uint8_t *pend_gal = nullptr; // 16-byte aligned global address of image byte 0
+    uint32_t pend_a0 = 0, pend_end = 0; // image bytes [a0, end) wait to be copied out (end = 0: nothing)
+    auto image_load = [&](uint32_t a0, uint32_t end, u32x4 (&v)[3], uint32_t &hb, uint32_t &tb) {
+        const uint8_t *img = ostage[wave];
+        const uint32_t c_lo = (a0 + 15u) / 16u, c_hi = end / 16u; // whole aligned chunks [c_lo, c_hi)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t c = c_lo + (uint32_t)lane + 64u * j;
+            if (c < c_hi) v[j] = *(const u32x4 *)(img + 16u * c);
+        }
+        // the bytes in front of the first and behind the last whole chunk (fewer than 16 each)
+        const uint32_t head_end = c_lo * 16u < end ? c_lo * 16u : end;
+        if (a0 + (uint32_t)lane < head_end) hb = img[a0 + lane];
+        const uint32_t tail0 = c_hi * 16u > head_end ? c_hi * 16u : head_end;
+        if (tail0 + (uint32_t)lane < end) tb = img[tail0 + lane];
+    };
+    auto image_store = [&](uint8_t *g_al, uint32_t a0, uint32_t end, const u32x4 (&v)[3], uint32_t hb, uint32_t tb) {
+        const uint32_t c_lo = (a0 + 15u) / 16u, c_hi = end / 16u;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t c = c_lo + (uint32_t)lane + 64u * j;
+            if (c < c_hi) *(u32x4 *)(g_al + 16u * c) = v[j];
+        }
+        const uint32_t head_end = c_lo * 16u < end ? c_lo * 16u : end;
+        if (a0 + (uint32_t)lane < head_end) g_al[a0 + lane] = (uint8_t)hb;
+        const uint32_t tail0 = c_hi * 16u > head_end ? c_hi * 16u : head_end;
+        if (tail0 + (uint32_t)lane < end) g_al[tail0 + lane] = (uint8_t)tb;
+    };
     const bool use_hist = HIST && P >= 128;
 
     if (tile < tc.ntiles) tc.template issue<AUX>(a.packed, tile, lds_wave, lane);
@@ -1407,6 +1441,11 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
             // the step's output: rows [s * row_step, ...) of the tile, contiguous bytes from step_g0 on
             uint8_t *const step_g0 = out_tile + (uint64_t)(s * row_step) * P;
             const uint32_t step_a0 = (uint32_t)((uintptr_t)step_g0 & 15u);
+            u32x4 iv[3];
+            uint32_t ihb = 0, itb = 0;
+            const bool copy_out = pend_end != 0; // wave-uniform
+            if (copy_out) image_load(pend_a0, pend_end, iv, ihb, itb);
+            asm volatile("" ::: "memory");
             if (row < rows_here && has_table) { // (rows beyond the column: nothing is written)
                 // the piece's RB bytes start at byte row * C of the tile: fetch the dwords around them, shift into place
                 const uint32_t byte0 = row * C;
@@ -1504,24 +1543,15 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
                 }
             }
             if (!use_hist && a.hits && ++since_flush == 31) flush_counts();
+            if (copy_out) image_store(pend_gal, pend_a0, pend_end, iv, ihb, itb);
+            pend_end = 0;
             if (staged) {
                 const uint32_t first = s * row_step;
                 const uint32_t rows_in_step = first >= rows_here ? 0u : (rows_here - first < row_step ? rows_here - first : row_step);
-                const uint32_t nbytes = rows_in_step * P;
-                if (nbytes) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's image is complete (LDS is in order per wave)
-                    const uint8_t *img = ostage[wave];
-                    const uint32_t end = step_a0 + nbytes;                // image bytes [step_a0, end)
-                    const uint32_t c_lo = (step_a0 + 15u) / 16u, c_hi = end / 16u; // whole aligned chunks [c_lo, c_hi)
-                    uint8_t *const g_al = step_g0 - step_a0;              // 16-byte aligned
-                    for (uint32_t c = c_lo + (uint32_t)lane; c < c_hi; c += 64)
-                        *(u32x4 *)(g_al + 16u * c) = *(const u32x4 *)(img + 16u * c);
-                    // the bytes in front of the first and behind the last whole chunk (fewer than 16 each)
-                    const uint32_t head_end = c_lo * 16u < end ? c_lo * 16u : end;
-                    if (step_a0 + (uint32_t)lane < head_end) g_al[step_a0 + lane] = img[step_a0 + lane];
-                    const uint32_t tail0 = c_hi * 16u > head_end ? c_hi * 16u : head_end;
-                    if (tail0 + (uint32_t)lane < end) g_al[tail0 + lane] = img[tail0 + lane];
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // image reads done before the next step overwrites it
+                if (rows_in_step) {
+                    pend_gal = step_g0 - step_a0;
+                    pend_a0 = step_a0;
+                    pend_end = step_a0 + rows_in_step * P;
                 }
             }
         }
@@ -1529,6 +1559,12 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
         const uint64_t next = tile + stride;
         if (next < tc.ntiles) tc.template issue<AUX>(a.packed, next, lds_wave, lane);
         tile = next;
+    }
+    if (pend_end) { // the wave's last image
+        u32x4 iv[3];
+        uint32_t ihb = 0, itb = 0;
+        image_load(pend_a0, pend_end, iv, ihb, itb);
+        image_store(pend_gal, pend_a0, pend_end, iv, ihb, itb);
     }
     if (!use_hist && a.hits) flush_counts();
     if constexpr (HIST) {
