@@ -82,7 +82,8 @@ struct ScanArgs {
                                // shared scans: 1 shared_wide_kernel drains its stores every tile; 2 per-group kernels instead of
                                // shared_wide2 / shared_linear; 4 rotate the 32-key rounds; 8 per-tile hit-count reductions; 16 P = 16
                                // linear one row per piece; 32 P = 2 on the LUT kernel; 64 compare chain; 128 shared_linear_kernel
-                               // whatever the width; 256 round 2's shared_linear_kernel instead of shared_linear2_kernel.  select_kernel (bits 9, 10 of the option arrive here as 2, 4): timing ablations
+                               // whatever the width; 256 round 2's shared_linear_kernel instead of shared_linear2_kernel; 0x200 .. 0x80000: round 3's
+                               // switches (0x20000 is set by the launcher: short last table attached).  select_kernel (bits 9, 10 of the option arrive here as 2, 4): timing ablations
     const uint8_t *packed2;    // scan2_kernel: the second column (same width, same n)
     uint32_t key2[2];          // scan2_kernel: second predicate as (lo, hi - lo)
     uint32_t invert2;          // scan2_kernel: negation word of the second predicate
