@@ -142,7 +142,7 @@ def block_select(tag):
     for s in chain:
         rows.append(f"| {s} | {chain[s]:.4f} ms | {fused[s]:.4f} ms | {chain[s] / fused[s]:.2f} × |")
     rows.append("")
-    rows.append(f"(1e9 rows × 9 bit, kernel chosen by the entry point's rule; `profiles/{tag}_next_rows_1e9x9.txt`; both kernels at every selectivity, same process: "
+    rows.append(f"(1e9 rows × 9 bit, `select2_kernel`; `profiles/{tag}_next_rows_1e9x9.txt`; both kernels at every selectivity, same process: "
                 f"`profiles/{tag}_select_ab.txt`)")
     return "\n".join(rows)
 
