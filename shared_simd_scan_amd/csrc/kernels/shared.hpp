@@ -1523,6 +1523,18 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
                             for (int i = 1; i < 8; i++) xi = quarter == (uint32_t)i ? x[i] : xi;
                             if (quarter < 8 && quarter < nvalid)
                                 __hip_atomic_fetch_add(&hist[xi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else if (T >= 4) {
+                            // four to seven lanes per row: values `quarter` and `quarter + T` -- two atomic instructions a step
+                            // instead of eight with a few lanes each
+                            uint32_t xa = x[0], xb = x[0];
+                            const uint32_t ib = quarter + T;
+#pragma unroll
+                            for (int i = 1; i < 8; i++) {
+                                xa = quarter == (uint32_t)i ? x[i] : xa;
+                                xb = ib == (uint32_t)i ? x[i] : xb;
+                            }
+                            if (quarter < nvalid) __hip_atomic_fetch_add(&hist[xa], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (ib < 8u && ib < nvalid) __hip_atomic_fetch_add(&hist[xb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         } else {
 #pragma unroll
                             for (int i = 0; i < 8 * RP; i++)
@@ -1793,6 +1805,16 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear2_kernel(ScanArgs 
                         for (int i = 1; i < 8; i++) xi = quarter == (uint32_t)i ? x[i] : xi;
                         if (quarter < 8 && quarter < nvalid)
                             __hip_atomic_fetch_add(&hist[xi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else if (Tq >= 4) { // values `quarter` and `quarter + Tq`: two atomic instructions a step instead of eight
+                        uint32_t xa = x[0], xb = x[0];
+                        const uint32_t ib = quarter + Tq;
+#pragma unroll
+                        for (int i = 1; i < 8; i++) {
+                            xa = quarter == (uint32_t)i ? x[i] : xa;
+                            xb = ib == (uint32_t)i ? x[i] : xb;
+                        }
+                        if (quarter < nvalid) __hip_atomic_fetch_add(&hist[xa], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (ib < 8u && ib < nvalid) __hip_atomic_fetch_add(&hist[xb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 8; i++)
