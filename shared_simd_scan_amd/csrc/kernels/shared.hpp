@@ -1293,6 +1293,8 @@ __device__ __forceinline__ void store_row_piece(uint8_t *p, const uint32_t (&y)[
     }
 }
 
+constexpr int kLinearImageBytes = 2048 + 64; // a wave-step's rows (<= 2 KiB) + the misalignment, rounded up
+
 template <int C, int AUX_, int RP>
 __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a)
 {
@@ -1312,8 +1314,9 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
     // stores) and leaves as ALIGNED 16-byte stores; only the < 16 bytes in front of the first and behind the last aligned
     // chunk go out as single bytes.  Unaligned 16-byte global stores (every piece of such a row) cost a quarter to a third of
     // the kernel: 2.5e8 x 9 bit with hit counts, P = 63 / 64: 2.9 / 3.9 TB/s, 257 / 256: 3.5 / 4.5, 385 / 384: 2.9 / 4.0.
-    constexpr int STAGE_BYTES = RP == 1 ? 2048 + 64 : 16;
-    __shared__ __attribute__((aligned(16))) uint8_t ostage[kWavesPerBlock][STAGE_BYTES];
+    // The image lives in DYNAMIC LDS behind the tables, kLinearImageBytes per wave, and only when the launcher asks for it (flags bit
+    // 20): as a static array it cost every launch of this kernel 8.4 KiB and with them a resident block at many key counts
+    // (aligned rows, same box: P = 128 0.96 -> 1.21 ms, P = 192 1.38 -> 1.83).
     __shared__ uint32_t s_hits[kMaxKeys];
     constexpr bool HIST = C <= 12; // hit counts by histogram of the values (see shared_wide2_kernel), else packed byte counters
     __shared__ uint32_t hist[HIST ? (1 << C) : 1];
@@ -1341,14 +1344,15 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
     // Copying the image out a step late (below) left every one of these figures where it was -- with it and flags bit 19 (the image at
     // every T) P = 9 / 17 with hit counts run at 0.67 / 0.72 x, P = 300 / 511 at 0.75 / 0.70 x of the direct stores: the image's LDS
     // traffic (unaligned ds_write_b128 + the read back), not a wait, is what it costs.
-    const bool staged = RP == 1 && C <= 10 && !aligned16 && !(a.flags & 0x4000u) && (T == 2 || (a.flags & 0x80000u));
+    const bool staged = RP == 1 && (a.flags & 0x100000u); // (the launcher's rule: linear_image_wanted())
+    uint8_t *const ostage_wave = mi355_dyn_lds + T * (uint32_t)(L::TABLE_DWORDS * 4) + (uint32_t)wave * kLinearImageBytes;
     // The image of step s leaves during step s + 1: its LDS reads are issued in front of that step's decode (a wave's LDS
     // operations execute in order, so they see step s's pieces and are not disturbed by step s + 1's, which follow them),
     // its global stores behind it -- the read latency passes behind the lookups and transposes instead of in front of the stores.
     uint8_t *pend_gal = nullptr; // 16-byte aligned global address of image byte 0
     uint32_t pend_a0 = 0, pend_end = 0; // image bytes [a0, end) wait to be copied out (end = 0: nothing)
     auto image_load = [&](uint32_t a0, uint32_t end, u32x4 (&v)[3], uint32_t &hb, uint32_t &tb) {
-        const uint8_t *img = ostage[wave];
+        const uint8_t *img = ostage_wave;
         const uint32_t c_lo = (a0 + 15u) / 16u, c_hi = end / 16u; // whole aligned chunks [c_lo, c_hi)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -1495,7 +1499,7 @@ __global__ __launch_bounds__(kBlockThreads) void shared_linear_kernel(ScanArgs a
                 } else if (staged) {
                     // the piece at its byte offset inside the step's image (which starts at the step's global misalignment, so
                     // that aligned chunks of the image are aligned chunks of memory)
-                    uint8_t *dst = ostage[wave] + step_a0 + (row - s * row_step) * P + 32u * quarter;
+                    uint8_t *dst = ostage_wave + step_a0 + (row - s * row_step) * P + 32u * quarter;
                     if (piece_bytes == 32) {
                         *(Unaligned16 *)dst = Unaligned16{y[0], y[1], y[2], y[3]};
                         *(Unaligned16 *)(dst + 16) = Unaligned16{y[4], y[5], y[6], y[7]};

@@ -54,8 +54,8 @@ inline int scan_bpc(int occ_bpc, int tile_bytes, const LaunchReq &r)
 // static LDS of the multi-pass LUT kernel: four tiles, the per-block hit counters, ticket word and slack
 template <int C, int VPL> constexpr size_t lut_static_lds()
 {
-    // + the hit-count histogram + shared_linear_kernel's output image (4 waves x 2112 bytes)
-    return 4 * ScanGeom<C, VPL>::LDS_BYTES + kMaxKeys * 4 + 512 + (C <= 12 ? (size_t)(4u << C) : 16) + 4 * 2112;
+    // + the hit-count histogram
+    return 4 * ScanGeom<C, VPL>::LDS_BYTES + kMaxKeys * 4 + 512 + (C <= 12 ? (size_t)(4u << C) : 16);
 }
 
 // the 32-keys-per-lookup kernel needs ceil(P/32) tables next to that in the CU's 160 KiB of LDS
@@ -326,7 +326,18 @@ template <int C> hipError_t launch_width(const LaunchReq &r)
                 // Rows of 65 and more keys with a short last table: attach_short() above decides between the two mappings.
                 else if ((r.scan.flags & 256u) ||
                          !(((r.scan.flags & 0x8000u) && P / 32 == 1 && P % 32 >= 1 && P % 32 <= 24) || (P < 32 && !r.scan.hits) || attach_short(P, r.scan.flags, r.scan.hits != nullptr)))
-                    hipLaunchKernelGGL((shared_linear_kernel<C, 2, 1>), lgrid, dim3(kBlockThreads), dyn, r.stream, r.scan);
+                {
+                    // rows of 33 .. 63 keys whose length is not a multiple of 16 bytes, single-table widths: through the wave-private
+                    // aligned output image (dynamic LDS behind the tables; flags bit 14: never, bit 19: at every row length, A/B)
+                    ScanArgs a1 = r.scan;
+                    size_t dyn1 = dyn;
+                    if (C <= 10 && (P & 15u) != 0 && !(r.scan.flags & 0x4000u) && ((P + 31) / 32 == 2 || (r.scan.flags & 0x80000u)) &&
+                        dyn + (size_t)kWavesPerBlock * kLinearImageBytes <= (size_t)max_dyn) {
+                        a1.flags |= 0x100000u;
+                        dyn1 += (size_t)kWavesPerBlock * kLinearImageBytes;
+                    }
+                    hipLaunchKernelGGL((shared_linear_kernel<C, 2, 1>), lgrid, dim3(kBlockThreads), dyn1, r.stream, a1);
+                }
                 else {
                     ScanArgs a2 = r.scan;
                     if (attach_short(P, r.scan.flags, r.scan.hits != nullptr)) a2.flags |= 0x20000u;
